@@ -1,0 +1,138 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference).
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
+
+Weights come from oracle.vqa_oracle.init_state_dict(cfg, seed) (this repo's own deterministic
+generator) and are loaded into the reference VQAModel with load_state_dict(strict=True); inputs
+come from oracle.vqa_oracle.synthetic_batch.  Only tensors (inputs' seeds, outputs, gradient
+summaries) are stored -- no reference source.  tests/test_oracle_golden.py regenerates the same
+weights/inputs from the seeds and checks the CPU oracle against the stored reference outputs.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from models.vqa_model import VQAModel  # noqa: E402  (the reference)
+from oracle import vqa_oracle as O  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+def checksum(sd):
+    keys = sorted(sd)
+    return np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in keys])
+
+
+def fixed_mask(B, L, lens):
+    lens = torch.tensor(lens)
+    return (torch.arange(L)[None, :] < lens[:, None]).long()
+
+
+def build(cfg, seed, jitter):
+    sd = O.init_state_dict(cfg, seed, jitter=jitter)
+    model = VQAModel(**cfg)
+    missing = model.load_state_dict(sd, strict=True)
+    assert list(model.state_dict().keys()) == [n for n, _, _ in O.param_shapes(cfg)], "state_dict order/layout"
+    return sd, model
+
+
+def grads_summary(model, names):
+    gd = dict(model.named_parameters())
+    norms = np.array([float(gd[n].grad.double().norm()) for n in names])
+    heads = np.stack([np.pad(gd[n].grad.flatten()[:64].numpy(), (0, max(0, 64 - gd[n].numel()))) for n in names])
+    return norms, heads
+
+
+def gen_full_eval():
+    cfg = O.full_config()
+    sd, model = build(cfg, seed=1, jitter=True)
+    model.eval()
+    images, ids, _, _ = O.synthetic_batch(4, seed=11)
+    mask = fixed_mask(4, 20, [20, 15, 7, 5])
+    with torch.no_grad():
+        logits, aux = model(images, ids, mask, return_aux=True)
+    top2 = logits.topk(2, dim=-1).values
+    np.savez_compressed(
+        os.path.join(OUT, "full_eval.npz"), weight_checksum=checksum(sd), logits=logits.numpy(),
+        margin=(top2[:, 0] - top2[:, 1]).numpy(), fused=aux["fused"].numpy(),
+        text_pooled=aux["text_pooled"].numpy(), attended_pooled=aux["attended_pooled"].numpy(),
+        text_features=aux["text_features"].numpy(), image_projected=aux["image_projected"].numpy(),
+        cross_w0=aux["cross_attention_weights"][0].numpy(), cross_w1=aux["cross_attention_weights"][1].numpy(),
+        image_features=aux["image_features"].numpy())
+    print("full_eval margins", (top2[:, 0] - top2[:, 1]).tolist())
+    # all-padding row -> NaN logits for that sample (text_encoder.py:244 -inf masking)
+    mask2 = mask.clone()
+    mask2[2] = 0
+    with torch.no_grad():
+        l2, _ = model(images, ids, mask2)
+    np.savez_compressed(os.path.join(OUT, "full_eval_allpad.npz"), logits=l2.numpy())
+    print("allpad nan rows", torch.isnan(l2).any(dim=1).tolist())
+
+
+def gen_full_train(tag, cfg, seed, B, image_size=224, seq_len=20, vocab=1000):
+    sd, model = build(cfg, seed=seed, jitter=True)
+    names = O.parameter_names(cfg)
+    model.train()
+    images, ids, mask, answers = O.synthetic_batch(B, seed=seed + 100, image_size=image_size, seq_len=seq_len,
+                                                   vocab=vocab, num_answers=cfg["num_answers"])
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999))
+    opt.zero_grad()
+    logits, aux = model(images, ids, mask, return_aux=True)
+    loss = torch.nn.CrossEntropyLoss()(logits, answers)
+    loss.backward()
+    norms, heads = grads_summary(model, names)
+    gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    opt.step()
+    delta = np.array([float((p.detach() - before[n]).double().norm()) for n, p in model.named_parameters()])
+    st = model.state_dict()
+    bn_keys = [k for k in st if "running_" in k]
+    np.savez_compressed(
+        os.path.join(OUT, f"{tag}.npz"), weight_checksum=checksum(sd), logits=logits.detach().numpy(),
+        loss=loss.item(), gnorm=float(gnorm), grad_norms=norms, grad_heads=heads, step_delta_norms=delta,
+        fused=aux["fused"].detach().numpy(), image_features=aux["image_features"].detach().numpy(),
+        bn_running=np.concatenate([st[k].numpy() for k in bn_keys]),
+        nbt=int(st["image_encoder.stem.1.num_batches_tracked"]))
+    print(tag, "loss", loss.item(), "gnorm", float(gnorm))
+
+
+def gen_overfit():
+    """reproduce_issue.py:16-76 behaviour: the small model overfits one batch (acc > 0.9 after 50 steps)."""
+    cfg = O.full_config(vocab_size=100, num_answers=10, embed_dim=32)
+    sd, model = build(cfg, seed=42, jitter=False)
+    g = torch.Generator().manual_seed(42)
+    images = torch.randn(4, 3, 224, 224, generator=g)
+    ids = torch.randint(0, 100, (4, 10), generator=g)
+    mask = torch.ones(4, 10)
+    targets = torch.tensor([1] * 4)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    model.train()
+    losses = []
+    for _ in range(50):
+        opt.zero_grad()
+        logits, _ = model(images, ids, mask)
+        loss = torch.nn.functional.cross_entropy(logits, targets)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    acc = (logits.argmax(-1) == targets).float().mean().item()
+    np.savez_compressed(os.path.join(OUT, "overfit.npz"), losses=np.array(losses), acc=acc)
+    print("overfit acc", acc, "final loss", losses[-1])
+
+
+if __name__ == "__main__":
+    gen_full_eval()
+    gen_full_train("full_train", O.full_config(dropout=0.0, answer_dropout=0.0), seed=2, B=4)
+    gen_full_train("small_train", O.full_config(dropout=0.0, answer_dropout=0.0, vocab_size=100, num_answers=10,
+                                                embed_dim=32), seed=3, B=2, image_size=64, seq_len=10, vocab=100)
+    gen_overfit()
