@@ -1,0 +1,138 @@
+"""GPU parity of the implicit-GEMM kernels (vqa_igemm / vqa_wgrad through the C ABI) against the oracle's
+ATen CPU convolutions on identical inputs.  fp32: exact-fp32 MFMA, tolerance 2e-4 of the output scale.
+bf16: operands are rounded to bf16 first so only accumulation order and the final bf16 rounding differ."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _pkg import sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tol(dtype):
+    return 2e-4 if dtype == torch.float32 else 1.2e-2
+
+
+def _round(t, dtype):
+    return t.to(dtype).float()
+
+
+def _relerr(got, ref):
+    return float((got - ref).abs().max() / ref.abs().max().clamp(min=1e-6))
+
+
+CONV_CASES = [  # B, Cin, Cout, H, R, stride, pad
+    (2, 64, 64, 12, 3, 1, 1),
+    (3, 64, 128, 14, 3, 2, 1),
+    (2, 128, 256, 9, 3, 1, 1),
+    (2, 64, 128, 14, 1, 2, 0),
+    (1, 256, 512, 7, 3, 2, 1),
+    (5, 128, 128, 28, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    K = sub("kernels")
+    B, Cin, Cout, H, R, stride, pad = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = _round(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = _round(torch.randn(Cout, Cin, R, R, generator=g) * (2.0 / (Cin * R * R)) ** 0.5, dtype)
+    Ho = (H + 2 * pad - R) // stride + 1
+    dy = _round(torch.randn(B, Cout, Ho, Ho, generator=g), dtype)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride=stride, padding=pad)
+    yr.backward(dy)
+
+    x_d = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)          # NHWC
+    w_krsc = w.permute(0, 2, 3, 1).contiguous().to(DEV)              # [Cout][R][S][Cin] fp32 master layout
+    dy_d = dy.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    M, Kw = B * Ho * Ho, R * R * Cin
+    geom = (B, H, H, Cin, Ho, Ho, R, R, stride, pad)
+    wp = K.pack_rows(w_krsc.view(Cout, Kw), dtype)
+    y, stats, mt = K.igemm(x_d, wp, M, Cout, Kw, geom, dtype=dtype, want_stats=True)
+    torch.cuda.synchronize()
+    y_ref = yr.detach().permute(0, 2, 3, 1).reshape(M, Cout)
+    assert _relerr(y.float().cpu(), y_ref) < _tol(dtype)
+    # BN partial statistics: column sums / sums of squares of the fp32 accumulators
+    s = stats.sum(dim=0).cpu()
+    assert _relerr(s[0], y_ref.sum(0)) < 5e-3 and _relerr(s[1], (y_ref ** 2).sum(0)) < 5e-3
+
+    # data gradient: transposed gather over dy with [Cin][R][S][Cout] weights
+    wt = K.pack_transpose(w_krsc.view(Cout, R * R, Cin), dtype)
+    Md = B * H * H
+    geom_d = (B, Ho, Ho, Cout, H, H, R, R, stride, pad)
+    dx, _, _ = K.igemm(dy_d, wt, Md, Cin, R * R * Cout, geom_d, dtype=dtype, transposed=1)
+    torch.cuda.synchronize()
+    dx_ref = xr.grad.permute(0, 2, 3, 1).reshape(Md, Cin)
+    assert _relerr(dx.float().cpu(), dx_ref) < _tol(dtype)
+
+    # weight gradient (fp32, accumulated with atomics into a zeroed buffer)
+    dw = torch.zeros(Cout, Kw, device=DEV, dtype=torch.float32)
+    K.wgrad(dy_d, x_d, dw, M, Cout, Kw, geom, dtype=dtype)
+    torch.cuda.synchronize()
+    dw_ref = wr.grad.permute(0, 2, 3, 1).reshape(Cout, Kw)
+    assert _relerr(dw.cpu(), dw_ref) < (2e-4 if dtype == torch.float32 else 3e-3)
+
+
+LIN_CASES = [(40, 256, 256), (80, 256, 1024), (17, 1024, 256), (4, 256, 1000), (33, 32, 10), (196, 512, 256), (2000, 256, 256)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", LIN_CASES)
+def test_linear_fwd_bwd_epilogues(case, dtype):
+    K = sub("kernels")
+    M, Kin, N = case
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = _round(torch.randn(M, Kin, generator=g), dtype)
+    w = _round(torch.randn(N, Kin, generator=g) / Kin ** 0.5, dtype)
+    b = torch.randn(N, generator=g)
+    res = _round(torch.randn(M, N, generator=g), dtype)
+    ref = torch.relu(x @ w.t() + b) + res
+    geom = K.linear_geom(M, Kin)
+    out, _, _ = K.igemm(x.to(DEV, dtype), K.pack_rows(w.to(DEV), dtype), M, N, Kin, geom, dtype=dtype, bias=b.to(DEV),
+                        relu=1, addend=res.to(DEV, dtype))
+    torch.cuda.synchronize()
+    assert _relerr(out.float().cpu(), ref) < _tol(dtype)
+    if N % 8 == 0:
+        dy = _round(torch.randn(M, N, generator=g), dtype)
+        wt = K.pack_transpose(w.to(DEV).view(N, 1, Kin), dtype)
+        dx, _, _ = K.igemm(dy.to(DEV, dtype), wt, M, Kin, N, K.linear_geom(M, N), dtype=dtype)
+        dw = torch.zeros(N, Kin, device=DEV)
+        K.wgrad(dy.to(DEV, dtype), x.to(DEV, dtype), dw, M, N, Kin, geom, dtype=dtype)
+        torch.cuda.synchronize()
+        assert _relerr(dx.float().cpu(), dy @ w) < _tol(dtype)
+        assert _relerr(dw.cpu(), dy.t() @ x) < (2e-4 if dtype == torch.float32 else 3e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_conv_fwd_wgrad(dtype):
+    K = sub("kernels")
+    B, H = 2, 40
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(B, 3, H, H, generator=g)
+    w = _round(torch.randn(64, 3, 7, 7, generator=g) * 0.1, dtype)
+    Ho = (H + 6 - 7) // 2 + 1
+    dy = _round(torch.randn(B, 64, Ho, Ho, generator=g), dtype)
+    img_r = _round(img, dtype)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(img_r, wr, None, stride=2, padding=3)
+    yr.backward(dy)
+    M = B * Ho * Ho
+    BK = 64 if dtype == torch.bfloat16 else 32
+    Kp = (147 + BK - 1) // BK * BK
+    w_krsc = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = K.pack_rows(w_krsc.view(64, 147), dtype, Kp)
+    geom = (B, H, H, 3, Ho, Ho, 7, 7, 2, 3)
+    y, stats, mt = K.igemm(img.to(DEV), wp, M, 64, Kp, geom, dtype=dtype, loader=K.LOADER_STEM, want_stats=True)
+    torch.cuda.synchronize()
+    y_ref = yr.detach().permute(0, 2, 3, 1).reshape(M, 64)
+    assert _relerr(y.float().cpu(), y_ref) < _tol(dtype)
+    dw = torch.zeros(64, 147, device=DEV)
+    K.wgrad(dy.permute(0, 2, 3, 1).contiguous().to(DEV, dtype), img.to(DEV), dw, M, 64, 147, geom, dtype=dtype, loader=K.LOADER_STEM)
+    torch.cuda.synchronize()
+    assert _relerr(dw.cpu(), wr.grad.permute(0, 2, 3, 1).reshape(64, 147)) < (2e-4 if dtype == torch.float32 else 3e-3)

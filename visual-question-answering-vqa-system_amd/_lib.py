@@ -1,0 +1,106 @@
+"""ctypes binding of libvqa_hip.so (the C ABI declared in include/vqa_hip.h).
+
+There is no fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+Every entry takes raw device pointers, explicit sizes and a hipStream_t; PyTorch owns all memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqa_hip.so")
+
+P, I, F, D, LL, ULL = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_ulonglong
+
+# name -> argument ctypes (all return int; last argument is always the stream unless noted)
+SIGNATURES = {
+    "vqa_igemm_mtiles": [I, I, I],
+    "vqa_igemm": [I, I, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, P],
+    "vqa_wgrad": [I, I, P, P, P] + [I] * 13 + [P],
+    "vqa_pack_rows": [I, P, P, I, I, I, P],
+    "vqa_pack_transpose": [I, P, P, I, I, I, P],
+    "vqa_bn_stats_finalize": [P, I, I, D, P, P, P, P, P, F, F, P, P, P],
+    "vqa_bn_eval_coef": [I, P, P, P, P, F, P, P],
+    "vqa_bn_apply": [I, P, P, P, P, P, LL, I, I, P],
+    "vqa_bn_bwd_blocks": [LL],
+    "vqa_bn_bwd_reduce": [I, P, P, P, P, P, P, P, LL, I, P],
+    "vqa_bn_bwd_finalize": [P, I, I, I, D, P, P, I, P, P, P, P],
+    "vqa_bn_bwd_apply": [I, P, P, P, P, P, P, P, P, LL, I, P],
+    "vqa_stem_pool_fwd": [I, P, P, P, P, I, I, I, I, P],
+    "vqa_stem_bwd_reduce": [I, P, P, P, P, P, I, I, I, I, P],
+    "vqa_stem_bwd_apply": [I, P, P, P, P, P, P, I, I, I, I, P],
+    "vqa_se_fwd": [I, P, P, P, P, P, P, P, I, I, I, I, P],
+    "vqa_se_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "vqa_spatial_fwd": [I, P, P, P, P, P, P, I, I, I, I, P],
+    "vqa_spatial_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "vqa_nhwc_to_nchw": [I, P, P, I, I, I, P],
+    "vqa_nchw_to_nhwc": [I, P, P, I, I, I, P],
+    "vqa_embed_fwd": [I, P, P, P, P, I, I, I, I, F, F, ULL, P],
+    "vqa_embed_bwd": [I, P, P, P, I, I, I, F, F, ULL, P],
+    "vqa_layernorm_fwd": [I, P, P, P, P, P, I, I, F, F, ULL, P, I, P],
+    "vqa_layernorm_bwd": [I, P, P, P, P, P, P, P, P, I, I, F, ULL, P, I, P],
+    "vqa_attention_fwd": [I, P, P, P, I, I, I, P, P, P, I, I, I, I, I, I, F, ULL, P],
+    "vqa_attention_bwd": [I, P, I, P, P, P, I, I, I, P, P, P, P, I, I, I, I, I, I, I, I, F, ULL, P],
+    "vqa_masked_pool_fwd": [I, P, P, P, I, I, I, I, I, P],
+    "vqa_masked_pool_bwd": [I, P, I, I, P, P, P, I, I, I, P],
+    "vqa_gate_fwd": [I, P, P, P, I, I, P],
+    "vqa_gate_bwd": [I, P, P, P, P, P, I, I, P],
+    "vqa_add": [I, P, P, P, LL, P],
+    "vqa_bias_act_bwd": [I, P, P, P, P, I, I, F, ULL, P],
+    "vqa_cross_entropy": [I, P, P, P, P, P, I, I, F, P],
+    "vqa_convert": [I, I, P, P, LL, P],
+    "vqa_sumsq": [P, LL, P, P],
+    "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P],
+}
+_NO_STATUS = {"vqa_igemm_mtiles", "vqa_bn_bwd_blocks"}   # return a count, not a status
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = I
+        _lib = L
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Invoke a status-returning entry on the current torch stream; raise on non-zero status."""
+    fn = getattr(lib(), name)
+    rc = fn(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with status {rc}" + (" (argument/shape error)" if rc == 1000 else " (hipError_t)"))
+
+
+def count(name: str, *args) -> int:
+    assert name in _NO_STATUS
+    return getattr(lib(), name)(*args)
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.float32:
+        return 0
+    if d == torch.bfloat16:
+        return 1
+    raise TypeError(f"unsupported dtype {d}")

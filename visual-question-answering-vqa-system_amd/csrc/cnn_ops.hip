@@ -1,0 +1,714 @@
+// HBM-bound CNN-side kernels for gfx950: BatchNorm (train statistics, apply, backward), the stem's fused
+// BN+ReLU+MaxPool, squeeze-excitation and spatial attention.  Activations are NHWC with T = float | bf16,
+// every per-channel statistic / coefficient is fp32, every global access is a 16-byte vector.
+//   BatchNorm2d        models/cnn_backbone.py:151,158,246,351 (nn.BatchNorm2d defaults)
+//   ReLU + MaxPool     models/cnn_backbone.py:352-353
+//   residual add+ReLU  models/cnn_backbone.py:194-195
+//   SEAttention        models/attention_modules.py:109-136
+//   SpatialAttention   models/attention_modules.py:223-243
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm statistics: reduce the igemm partial slab [tiles][2][C] -> mean / invstd / scale / shift
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_reduce_partials_kernel(const float* __restrict__ part, double* __restrict__ acc, int tiles, int C) {
+  // grid (ceil(C/64), G); block 256 = 4 tile-lanes x 64 channels
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), tl = threadIdx.x >> 6;
+  __shared__ double sh[2][4][64];
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int t = blockIdx.y * 4 + tl; t < tiles; t += gridDim.y * 4) {
+      s += (double)part[((size_t)t * 2) * C + c];
+      q += (double)part[((size_t)t * 2 + 1) * C + c];
+    }
+  sh[0][tl][threadIdx.x & 63] = s; sh[1][tl][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    for (int i = 1; i < 4; ++i) { s += sh[0][i][threadIdx.x]; q += sh[1][i][threadIdx.x]; }
+    acc[((size_t)blockIdx.y * 2) * C + c] = s;
+    acc[((size_t)blockIdx.y * 2 + 1) * C + c] = q;
+  }
+}
+
+// coef layout (fp32, 4*C): scale | shift | mean | invstd
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, int G, int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var, long long* nbt,
+                                   float momentum, float eps, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int g = 0; g < G; ++g) { s += acc[((size_t)g * 2) * C + c]; q += acc[((size_t)g * 2 + 1) * C + c]; }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  coef[c] = sc; coef[C + c] = beta[c] - (float)mean * sc; coef[2 * C + c] = (float)mean; coef[3 * C + c] = invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    if (c == 0 && nbt) *nbt += 1;
+  }
+}
+
+__global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * invstd;
+  coef[c] = sc; coef[C + c] = beta[c] - rm[c] * sc; coef[2 * C + c] = rm[c]; coef[3 * C + c] = invstd;
+}
+
+// out = [relu]( y*scale+shift  [+ res*rscale+rshift | + res] )
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ coef, const T* __restrict__ res,
+                                const float* __restrict__ rcoef, T* __restrict__ out, size_t nvec, int C, int relu) {
+  constexpr int VEC = Vec16<T>::N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)((i * VEC) % C);
+    Vec16<T> v = ldg16(y + i * VEC), r, o;
+    if (res) r = ldg16(res + i * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float x = v.get(j) * coef[c0 + j] + coef[C + c0 + j];
+      if (res) x += rcoef ? (r.get(j) * rcoef[c0 + j] + rcoef[C + c0 + j]) : r.get(j);
+      o.set(j, relu ? fmaxf(x, 0.f) : x);
+    }
+    stg16(out + i * VEC, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward.  g = dout * (out > 0) (relu) or dout.  Partial sums per block -> slab [blocks][3][C]:
+//   0: sum g   1: sum g*xhat(y)   2: sum g*xhat(y2) (second BN sharing g: the 1x1 shortcut)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ outact, const T* __restrict__ y,
+                                                            const float* __restrict__ coef, const T* __restrict__ y2,
+                                                            const float* __restrict__ coef2, float* __restrict__ slab, size_t rows, int C) {
+  constexpr int VEC = Vec16<T>::N;
+  const int cv = C / VEC;                 // vectors per row
+  const int lanes_r = 256 / cv;           // rows processed concurrently by the block (C <= 256*VEC)
+  const int myv = threadIdx.x % cv, myr = threadIdx.x / cv;
+  float sg[VEC], sx[VEC], sx2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sg[j] = sx[j] = sx2[j] = 0.f;
+  if (myr < lanes_r) {
+    const int c0 = myv * VEC;
+    for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
+      const size_t off = r * C + c0;
+      Vec16<T> d = ldg16(dout + off), yy = ldg16(y + off), o, y2v;
+      if (outact) o = ldg16(outact + off);
+      if (y2) y2v = ldg16(y2 + off);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float g = d.get(j);
+        if (outact && !(o.get(j) > 0.f)) g = 0.f;
+        sg[j] += g;
+        sx[j] += g * (yy.get(j) - coef[2 * C + c0 + j]) * coef[3 * C + c0 + j];
+        if (y2) sx2[j] += g * (y2v.get(j) - coef2[2 * C + c0 + j]) * coef2[3 * C + c0 + j];
+      }
+    }
+  }
+  extern __shared__ float shm[];          // [3][256][VEC]
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    shm[(0 * 256 + threadIdx.x) * VEC + j] = sg[j];
+    shm[(1 * 256 + threadIdx.x) * VEC + j] = sx[j];
+    shm[(2 * 256 + threadIdx.x) * VEC + j] = sx2[j];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 3 * C; o += 256) {
+    const int k = o / C, c = o - k * C, v = c / VEC, j = c - v * VEC;
+    float s = 0.f;
+    for (int r = 0; r < lanes_r; ++r) s += shm[(k * 256 + r * cv + v) * VEC + j];
+    slab[((size_t)blockIdx.x * 3 + k) * C + c] = s;
+  }
+}
+
+// reduce slab over blocks; emit dgamma/dbeta (+=) and the apply coefficients  dy = A*g + Bc*y + Cc
+// bcoef layout (3*C): A | Bc | Cc
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nblk, int C, int which, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ coef, int training,
+                                       float* dgamma, float* dbeta, float* __restrict__ bcoef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sx = 0.0;
+  for (int b = 0; b < nblk; ++b) { sg += slab[((size_t)b * 3) * C + c]; sx += slab[((size_t)b * 3 + which) * C + c]; }
+  if (dgamma) dgamma[c] += (float)sx;
+  if (dbeta) dbeta[c] += (float)sg;
+  const float mean = coef[2 * C + c], invstd = coef[3 * C + c], gi = gamma[c] * invstd;
+  if (training) {
+    const float mg = (float)(sg / count), mgx = (float)(sx / count);
+    bcoef[c] = gi; bcoef[C + c] = -gi * invstd * mgx; bcoef[2 * C + c] = gi * (mean * invstd * mgx - mg);
+  } else { bcoef[c] = gi; bcoef[C + c] = 0.f; bcoef[2 * C + c] = 0.f; }
+}
+
+// dy = A*g + B*y + C ; optional second output dy2 = A2*g + B2*y2 + C2 ; optional gout = g (T) for the identity path
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ outact, const T* __restrict__ y,
+                                    const float* __restrict__ bc, T* __restrict__ dy, const T* __restrict__ y2,
+                                    const float* __restrict__ bc2, T* __restrict__ dy2, size_t nvec, int C) {
+  constexpr int VEC = Vec16<T>::N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)((i * VEC) % C);
+    Vec16<T> d = ldg16(dout + i * VEC), yy = ldg16(y + i * VEC), o, y2v, r, r2;
+    if (outact) o = ldg16(outact + i * VEC);
+    if (y2) y2v = ldg16(y2 + i * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float g = d.get(j);
+      if (outact && !(o.get(j) > 0.f)) g = 0.f;
+      r.set(j, bc[c0 + j] * g + bc[C + c0 + j] * yy.get(j) + bc[2 * C + c0 + j]);
+      if (y2) r2.set(j, bc2[c0 + j] * g + bc2[C + c0 + j] * y2v.get(j) + bc2[2 * C + c0 + j]);
+    }
+    stg16(dy + i * VEC, r);
+    if (y2) stg16(dy2 + i * VEC, r2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem tail: BN + ReLU + MaxPool3x3/2 p1 fused (the 112x112 activation is never written)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void stem_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef, T* __restrict__ out,
+                                     uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo) {
+  constexpr int VEC = Vec16<T>::N;
+  const int cv = C / VEC;
+  const size_t total = (size_t)B * Ho * Wo * cv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv); size_t p = i / cv;
+    const int ow = (int)(p % Wo); p /= Wo; const int oh = (int)(p % Ho); const int b = (int)(p / Ho);
+    const int c0 = v * VEC;
+    float best[VEC]; int bi[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    for (int r = 0; r < 3; ++r) {
+      const int ih = oh * 2 - 1 + r;
+      if (ih < 0 || ih >= H) continue;
+      for (int s = 0; s < 3; ++s) {
+        const int iw = ow * 2 - 1 + s;
+        if (iw < 0 || iw >= W) continue;
+        Vec16<T> yy = ldg16(y + (((size_t)b * H + ih) * W + iw) * C + c0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float a = fmaxf(yy.get(j) * coef[c0 + j] + coef[C + c0 + j], 0.f);
+          if (a > best[j]) { best[j] = a; bi[j] = r * 3 + s; }     // first max wins (ATen max_pool2d)
+        }
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { o.set(j, best[j]); idx[i * VEC + j] = (uint8_t)bi[j]; }
+    stg16(out + i * VEC, o);
+  }
+}
+
+// gradient wrt the (virtual) 112x112 post-ReLU activation, routed through the pool argmax and the ReLU mask
+template <typename T>
+__device__ __forceinline__ void stem_route(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const Vec16<T>& yy,
+                                           const float* __restrict__ coef, int b, int h, int w, int c0, int C, int Ho, int Wo, float* g) {
+  constexpr int VEC = Vec16<T>::N;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) g[j] = 0.f;
+  for (int oh = (h > 0 ? (h - 1) / 2 : 0); oh <= (h + 1) / 2; ++oh) {       // windows with oh*2-1 <= h <= oh*2+1
+    if (oh >= Ho) continue;
+    const int r = h - (oh * 2 - 1);
+    if (r < 0 || r > 2) continue;
+    for (int ow = (w > 0 ? (w - 1) / 2 : 0); ow <= (w + 1) / 2; ++ow) {
+      if (ow >= Wo) continue;
+      const int s = w - (ow * 2 - 1);
+      if (s < 0 || s > 2) continue;
+      const size_t o = (((size_t)b * Ho + oh) * Wo + ow) * C + c0;
+      Vec16<T> d = ldg16(dpool + o);
+      uint64_t w0;
+      if constexpr (VEC == 8) w0 = *reinterpret_cast<const uint64_t*>(idx + o);
+      else w0 = *reinterpret_cast<const uint32_t*>(idx + o);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int id = (int)((w0 >> (8 * j)) & 0xff);
+        if (id == r * 3 + s) g[j] += d.get(j);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j)
+    if (!(yy.get(j) * coef[c0 + j] + coef[C + c0 + j] > 0.f)) g[j] = 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ y,
+                                                              const float* __restrict__ coef, float* __restrict__ slab,
+                                                              int B, int H, int W, int C, int Ho, int Wo) {
+  constexpr int VEC = Vec16<T>::N;
+  const int cv = C / VEC, lanes_r = 256 / cv;
+  const int myv = threadIdx.x % cv, myr = threadIdx.x / cv, c0 = myv * VEC;
+  const size_t rows = (size_t)B * H * W;
+  float sg[VEC], sx[VEC], g[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sg[j] = sx[j] = 0.f;
+  if (myr < lanes_r)
+    for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
+      const int w = (int)(r % W); size_t q = r / W; const int h = (int)(q % H); const int b = (int)(q / H);
+      Vec16<T> yy = ldg16(y + r * C + c0);
+      stem_route<T>(dpool, idx, yy, coef, b, h, w, c0, C, Ho, Wo, g);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { sg[j] += g[j]; sx[j] += g[j] * (yy.get(j) - coef[2 * C + c0 + j]) * coef[3 * C + c0 + j]; }
+    }
+  extern __shared__ float shm[];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { shm[(0 * 256 + threadIdx.x) * VEC + j] = sg[j]; shm[(1 * 256 + threadIdx.x) * VEC + j] = sx[j]; }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += 256) {
+    const int k = o / C, c = o - k * C, v = c / VEC, j = c - v * VEC;
+    float s = 0.f;
+    for (int r = 0; r < lanes_r; ++r) s += shm[(k * 256 + r * cv + v) * VEC + j];
+    slab[((size_t)blockIdx.x * 3 + k) * C + c] = s;
+    if (k == 0) slab[((size_t)blockIdx.x * 3 + 2) * C + c] = 0.f;
+  }
+}
+
+template <typename T>
+__global__ void stem_bwd_apply_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ y,
+                                      const float* __restrict__ coef, const float* __restrict__ bc, T* __restrict__ dy,
+                                      int B, int H, int W, int C, int Ho, int Wo) {
+  constexpr int VEC = Vec16<T>::N;
+  const int cv = C / VEC;
+  const size_t total = (size_t)B * H * W * cv;
+  float g[VEC];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % cv); size_t r = i / cv;
+    const int w = (int)(r % W); size_t q = r / W; const int h = (int)(q % H); const int b = (int)(q / H);
+    const int c0 = v * VEC;
+    Vec16<T> yy = ldg16(y + i * VEC), o;
+    stem_route<T>(dpool, idx, yy, coef, b, h, w, c0, C, Ho, Wo, g);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.set(j, bc[c0 + j] * g[j] + bc[C + c0 + j] * yy.get(j) + bc[2 * C + c0 + j]);
+    stg16(dy + i * VEC, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Squeeze-excitation.  One workgroup per sample.
+// ---------------------------------------------------------------------------------------------
+// se buffers (fp32): pooled[B][C], hidden[B][Cr], scale[B][C]
+template <typename T>
+__global__ __launch_bounds__(256) void se_pool_fc_kernel(const T* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                         float* __restrict__ pooled, float* __restrict__ hidden, float* __restrict__ scale,
+                                                         int HW, int C, int Cr) {
+  constexpr int VEC = Vec16<T>::N;
+  extern __shared__ float sh[];            // [256*VEC] scratch, then pooled[C], hidden[Cr]
+  const int b = blockIdx.x, cv = C / VEC, lanes_r = 256 / cv;
+  const int myv = threadIdx.x % cv, myr = threadIdx.x / cv;
+  float s[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  if (myr < lanes_r)
+    for (int p = myr; p < HW; p += lanes_r) {
+      Vec16<T> v = ldg16(x + ((size_t)b * HW + p) * C + myv * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += v.get(j);
+    }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sh[threadIdx.x * VEC + j] = s[j];
+  __syncthreads();
+  float* pl = sh + 256 * VEC; float* hd = pl + C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int v = c / VEC, j = c - v * VEC;
+    float t = 0.f;
+    for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
+    t /= (float)HW;
+    pl[c] = t; pooled[(size_t)b * C + c] = t;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int jr = wave; jr < Cr; jr += 4) {
+    float t = 0.f;
+    for (int c = lane; c < C; c += 64) t += w1[(size_t)jr * C + c] * pl[c];
+    t = wave_sum(t);
+    if (lane == 0) { t = fmaxf(t, 0.f); hd[jr] = t; hidden[(size_t)b * Cr + jr] = t; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int jr = 0; jr < Cr; ++jr) t += w2[(size_t)c * Cr + jr] * hd[jr];
+    scale[(size_t)b * C + c] = 1.f / (1.f + expf(-t));
+  }
+}
+
+// out = x * rowscale[b][c] * pixscale[b][hw]   (either scale may be null)
+template <typename T>
+__global__ void scale_kernel(const T* __restrict__ x, const float* __restrict__ chscale, const float* __restrict__ pixscale,
+                             T* __restrict__ out, size_t nvec, int HW, int C) {
+  constexpr int VEC = Vec16<T>::N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * VEC; const int c0 = (int)(e % C); const size_t pix = e / C; const size_t b = pix / HW;
+    Vec16<T> v = ldg16(x + e), o;
+    const float ps = pixscale ? pixscale[pix] : 1.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.set(j, v.get(j) * ps * (chscale ? chscale[b * C + c0 + j] : 1.f));
+    stg16(out + e, o);
+  }
+}
+
+// SE backward, per sample: ds[c] = sum_hw dout*x ; through sigmoid / fc2 / relu / fc1 -> dz2[B][C], dh[B][Cr], dpool[B][C]
+template <typename T>
+__global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ w1,
+                                                            const float* __restrict__ w2, const float* __restrict__ hidden,
+                                                            const float* __restrict__ scale, float* __restrict__ dz2, float* __restrict__ dh,
+                                                            float* __restrict__ dpool, int HW, int C, int Cr) {
+  constexpr int VEC = Vec16<T>::N;
+  extern __shared__ float sh[];
+  const int b = blockIdx.x, cv = C / VEC, lanes_r = 256 / cv;
+  const int myv = threadIdx.x % cv, myr = threadIdx.x / cv;
+  float s[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  if (myr < lanes_r)
+    for (int p = myr; p < HW; p += lanes_r) {
+      const size_t off = ((size_t)b * HW + p) * C + myv * VEC;
+      Vec16<T> d = ldg16(dout + off), v = ldg16(x + off);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += d.get(j) * v.get(j);
+    }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sh[threadIdx.x * VEC + j] = s[j];
+  __syncthreads();
+  float* z2 = sh + 256 * VEC; float* dhs = z2 + C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int v = c / VEC, j = c - v * VEC;
+    float t = 0.f;
+    for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
+    const float sg = scale[(size_t)b * C + c];
+    t *= sg * (1.f - sg);
+    z2[c] = t; dz2[(size_t)b * C + c] = t;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int jr = wave; jr < Cr; jr += 4) {
+    float t = 0.f;
+    for (int c = lane; c < C; c += 64) t += z2[c] * w2[(size_t)c * Cr + jr];
+    t = wave_sum(t);
+    if (lane == 0) { t = hidden[(size_t)b * Cr + jr] > 0.f ? t : 0.f; dhs[jr] = t; dh[(size_t)b * Cr + jr] = t; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int jr = 0; jr < Cr; ++jr) t += dhs[jr] * w1[(size_t)jr * C + c];
+    dpool[(size_t)b * C + c] = t;
+  }
+}
+
+// dx = dout*scale[b][c] + dpool[b][c]/HW
+template <typename T>
+__global__ void se_bwd_apply_kernel(const T* __restrict__ dout, const float* __restrict__ scale, const float* __restrict__ dpool,
+                                    T* __restrict__ dx, size_t nvec, int HW, int C) {
+  constexpr int VEC = Vec16<T>::N;
+  const float inv = 1.f / (float)HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * VEC; const int c0 = (int)(e % C); const size_t b = e / C / HW;
+    Vec16<T> d = ldg16(dout + e), o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.set(j, d.get(j) * scale[b * C + c0 + j] + dpool[b * C + c0 + j] * inv);
+    stg16(dx + e, o);
+  }
+}
+
+// dw2[c][j] += sum_b dz2[b][c]*hidden[b][j] ; dw1[j][c] += sum_b dh[b][j]*pooled[b][c]
+__global__ void se_wgrad_kernel(const float* __restrict__ dz2, const float* __restrict__ hidden, const float* __restrict__ dh,
+                                const float* __restrict__ pooled, float* dw1, float* dw2, int B, int C, int Cr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * Cr) return;
+  { const int c = i / Cr, j = i - c * Cr; float t = 0.f;
+    for (int b = 0; b < B; ++b) t += dz2[(size_t)b * C + c] * hidden[(size_t)b * Cr + j];
+    dw2[i] += t; }
+  { const int j = i / C, c = i - j * C; float t = 0.f;
+    for (int b = 0; b < B; ++b) t += dh[(size_t)b * Cr + j] * pooled[(size_t)b * C + c];
+    dw1[i] += t; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Spatial attention.  pooled2[B][H][W][2] fp32 (max, mean), amax[B][H][W] int (argmax channel), amap[B][H][W] fp32
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void spatial_pool_kernel(const T* __restrict__ x, float* __restrict__ pooled2, int* __restrict__ amax, size_t npix, int C) {
+  constexpr int VEC = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const size_t wid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t p = wid; p < npix; p += nw) {
+    float mx = -INFINITY, sm = 0.f; int mi = 0x7fffffff;
+    for (int c0 = lane * VEC; c0 < C; c0 += 64 * VEC) {
+      Vec16<T> v = ldg16(x + p * C + c0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { const float f = v.get(j); sm += f; if (f > mx) { mx = f; mi = c0 + j; } }
+    }
+    sm = wave_sum(sm);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {      // max with lowest-index tie-break (torch.max picks the first maximum)
+      const float om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(mi, o, 64);
+      if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+    }
+    if (lane == 0) { pooled2[p * 2] = mx; pooled2[p * 2 + 1] = sm / (float)C; amax[p] = mi; }
+  }
+}
+
+// amap = sigmoid(conv7x7(pooled2; w[2][7][7]))   (w is the (1,2,7,7) parameter, ch-major)
+__global__ void spatial_conv_kernel(const float* __restrict__ pooled2, const float* __restrict__ w, float* __restrict__ amap, int B, int H, int W) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * H * W) return;
+  const int ww = (int)(i % W); size_t q = i / W; const int h = (int)(q % H); const int b = (int)(q / H);
+  float t = 0.f;
+  for (int r = 0; r < 7; ++r) {
+    const int ih = h + r - 3; if (ih < 0 || ih >= H) continue;
+    for (int s = 0; s < 7; ++s) {
+      const int iw = ww + s - 3; if (iw < 0 || iw >= W) continue;
+      const float* pp = pooled2 + (((size_t)b * H + ih) * W + iw) * 2;
+      t += pp[0] * w[r * 7 + s] + pp[1] * w[49 + r * 7 + s];
+    }
+  }
+  amap[i] = 1.f / (1.f + expf(-t));
+}
+
+// dpre[p] = (sum_c dout*x) * a*(1-a)
+template <typename T>
+__global__ void spatial_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ amap,
+                                          float* __restrict__ dpre, size_t npix, int C) {
+  constexpr int VEC = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const size_t wid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t p = wid; p < npix; p += nw) {
+    float s = 0.f;
+    for (int c0 = lane * VEC; c0 < C; c0 += 64 * VEC) {
+      Vec16<T> d = ldg16(dout + p * C + c0), v = ldg16(x + p * C + c0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s += d.get(j) * v.get(j);
+    }
+    s = wave_sum(s);
+    if (lane == 0) { const float a = amap[p]; dpre[p] = s * a * (1.f - a); }
+  }
+}
+
+// dpool2[b][h][w][ch] = sum_{r,s} dpre[b][h-r+3][w-s+3] * w[ch][r][s]
+__global__ void spatial_bwd_conv_kernel(const float* __restrict__ dpre, const float* __restrict__ w, float* __restrict__ dpool2, int B, int H, int W) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * H * W) return;
+  const int ww = (int)(i % W); size_t q = i / W; const int h = (int)(q % H); const int b = (int)(q / H);
+  float t0 = 0.f, t1 = 0.f;
+  for (int r = 0; r < 7; ++r) {
+    const int oh = h - r + 3; if (oh < 0 || oh >= H) continue;
+    for (int s = 0; s < 7; ++s) {
+      const int ow = ww - s + 3; if (ow < 0 || ow >= W) continue;
+      const float d = dpre[((size_t)b * H + oh) * W + ow];
+      t0 += d * w[r * 7 + s]; t1 += d * w[49 + r * 7 + s];
+    }
+  }
+  dpool2[i * 2] = t0; dpool2[i * 2 + 1] = t1;
+}
+
+// dx = dout*amap[p] + dpool2[p][1]/C + (c == amax[p]) * dpool2[p][0]
+template <typename T>
+__global__ void spatial_bwd_apply_kernel(const T* __restrict__ dout, const float* __restrict__ amap, const float* __restrict__ dpool2,
+                                         const int* __restrict__ amax, T* __restrict__ dx, size_t nvec, int C) {
+  constexpr int VEC = Vec16<T>::N;
+  const float inv = 1.f / (float)C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * VEC; const int c0 = (int)(e % C); const size_t p = e / C;
+    Vec16<T> d = ldg16(dout + e), o;
+    const float a = amap[p], dm = dpool2[p * 2], da = dpool2[p * 2 + 1] * inv; const int mi = amax[p];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.set(j, d.get(j) * a + da + ((c0 + j) == mi ? dm : 0.f));
+    stg16(dx + e, o);
+  }
+}
+
+// dw[ch][r][s] += sum_{b,h,w} dpre[b][h][w] * pooled2[b][h+r-3][w+s-3][ch] ; one block per (ch,r,s)
+__global__ __launch_bounds__(256) void spatial_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ pooled2, float* dw, int B, int H, int W) {
+  const int o = blockIdx.x, ch = o / 49, r = (o % 49) / 7, s = o % 7;
+  float t = 0.f;
+  const size_t n = (size_t)B * H * W;
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    const int ww = (int)(i % W); size_t q = i / W; const int h = (int)(q % H); const int b = (int)(q / H);
+    const int ih = h + r - 3, iw = ww + s - 3;
+    if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+    t += dpre[i] * pooled2[(((size_t)b * H + ih) * W + iw) * 2 + ch];
+  }
+  __shared__ float sh[4];
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) dw[o] += sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// NHWC(T) <-> NCHW(fp32) boundary conversions (aux['image_features'] is NCHW fp32 at the API boundary)
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int HW, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * HW * C) return;
+  const int p = (int)(i % HW); size_t q = i / HW; const int c = (int)(q % C); const size_t b = q / C;
+  out[i] = to_f<T>(in[(b * HW + p) * C + c]);
+}
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int HW, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * HW * C) return;
+  const int c = (int)(i % C); size_t q = i / C; const int p = (int)(q % HW); const size_t b = q / HW;
+  out[i] = from_f<T>(in[(b * C + c) * HW + p]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+static inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 16384 ? 16384 : (g ? g : 1)); }
+#define DT(call_f, call_b) do { if (dtype) { call_b; } else { call_f; } } while (0)
+
+extern "C" {
+
+// part: igemm slab [tiles][2][C]; scratch: >= 64*2*C doubles; coef out: 4*C floats. running_* / nbt may be null.
+int vqa_bn_stats_finalize(const float* part, int tiles, int C, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, long long* nbt, float momentum, float eps,
+                          double* scratch, float* coef, hipStream_t st) {
+  if (!part || !scratch || !coef || tiles <= 0 || C <= 0) return VQA_EARG;
+  int G = (tiles + 63) / 64; if (G > 64) G = 64; if (G < 1) G = 1;
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((C + 63) / 64, G), dim3(256), 0, st, part, scratch, tiles, C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, G, C, count, gamma, beta,
+                     running_mean, running_var, nbt, momentum, eps, coef);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_bn_eval_coef(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* coef, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta, rm, rv, eps, coef);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_bn_apply(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, void* out, long long numel, int C, int relu, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  if (C % VEC || numel % C) return VQA_EARG;
+  const size_t nvec = (size_t)numel / VEC;
+  DT(hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)y, coef, (const float*)res, rcoef, (float*)out, nvec, C, relu),
+     hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)y, coef, (const bf16_t*)res, rcoef, (bf16_t*)out, nvec, C, relu));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_bn_bwd_blocks(long long rows) { long long g = (rows + 63) / 64; return (int)(g > 1024 ? 1024 : (g < 1 ? 1 : g)); }
+// slab: [vqa_bn_bwd_blocks(rows)][3][C] floats
+int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const void* y, const float* coef, const void* y2, const float* coef2,
+                      float* slab, long long rows, int C, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  const int nb = vqa_bn_bwd_blocks(rows);
+  const size_t shm = (size_t)3 * 256 * VEC * 4;
+  DT(hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb), dim3(256), shm, st, (const float*)dout, (const float*)outact, (const float*)y, coef, (const float*)y2, coef2, slab, (size_t)rows, C),
+     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)outact, (const bf16_t*)y, coef, (const bf16_t*)y2, coef2, slab, (size_t)rows, C));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_bn_bwd_finalize(const float* slab, int nblk, int C, int which, double count, const float* gamma, const float* coef, int training,
+                        float* dgamma, float* dbeta, float* bcoef, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, slab, nblk, C, which, count, gamma, coef, training, dgamma, dbeta, bcoef);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_bn_bwd_apply(int dtype, const void* dout, const void* outact, const void* y, const float* bc, void* dy,
+                     const void* y2, const float* bc2, void* dy2, long long numel, int C, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  if (C % VEC || numel % C) return VQA_EARG;
+  const size_t nvec = (size_t)numel / VEC;
+  DT(hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)dout, (const float*)outact, (const float*)y, bc, (float*)dy, (const float*)y2, bc2, (float*)dy2, nvec, C),
+     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (const bf16_t*)y, bc, (bf16_t*)dy, (const bf16_t*)y2, bc2, (bf16_t*)dy2, nvec, C));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+
+int vqa_stem_pool_fwd(int dtype, const void* y, const float* coef, void* out, uint8_t* idx, int B, int H, int W, int C, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  if (C % 8) return VQA_EARG;
+  const size_t total = (size_t)B * Ho * Wo * (C / VEC);
+  DT(hipLaunchKernelGGL(stem_pool_fwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, st, (const float*)y, coef, (float*)out, idx, B, H, W, C, Ho, Wo),
+     hipLaunchKernelGGL(stem_pool_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, st, (const bf16_t*)y, coef, (bf16_t*)out, idx, B, H, W, C, Ho, Wo));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_stem_bwd_reduce(int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* coef, float* slab, int B, int H, int W, int C, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  if (C % 8 || 256 % (C / VEC)) return VQA_EARG;
+  const int nb = vqa_bn_bwd_blocks((long long)B * H * W);
+  const size_t shm = (size_t)2 * 256 * VEC * 4;
+  DT(hipLaunchKernelGGL(stem_bwd_reduce_kernel<float>, dim3(nb), dim3(256), shm, st, (const float*)dpool, idx, (const float*)y, coef, slab, B, H, W, C, Ho, Wo),
+     hipLaunchKernelGGL(stem_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), shm, st, (const bf16_t*)dpool, idx, (const bf16_t*)y, coef, slab, B, H, W, C, Ho, Wo));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_stem_bwd_apply(int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* coef, const float* bc, void* dy, int B, int H, int W, int C, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)B * H * W * (C / VEC);
+  DT(hipLaunchKernelGGL(stem_bwd_apply_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, st, (const float*)dpool, idx, (const float*)y, coef, bc, (float*)dy, B, H, W, C, Ho, Wo),
+     hipLaunchKernelGGL(stem_bwd_apply_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, st, (const bf16_t*)dpool, idx, (const bf16_t*)y, coef, bc, (bf16_t*)dy, B, H, W, C, Ho, Wo));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+
+int vqa_se_fwd(int dtype, const void* x, const float* w1, const float* w2, float* pooled, float* hidden, float* scale, void* out,
+               int B, int HW, int C, int Cr, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  const size_t shm = ((size_t)256 * VEC + C + Cr) * 4;
+  DT(hipLaunchKernelGGL(se_pool_fc_kernel<float>, dim3(B), dim3(256), shm, st, (const float*)x, w1, w2, pooled, hidden, scale, HW, C, Cr),
+     hipLaunchKernelGGL(se_pool_fc_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)x, w1, w2, pooled, hidden, scale, HW, C, Cr));
+  const size_t nvec = (size_t)B * HW * C / VEC;
+  DT(hipLaunchKernelGGL(scale_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, scale, (const float*)nullptr, (float*)out, nvec, HW, C),
+     hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x, scale, (const float*)nullptr, (bf16_t*)out, nvec, HW, C));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+// scratch: dz2[B*C] | dh[B*Cr] | dpool[B*C] floats
+int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, const float* w2, const float* pooled, const float* hidden,
+               const float* scale, float* scratch, void* dx, float* dw1, float* dw2, int B, int HW, int C, int Cr, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  float* dz2 = scratch; float* dh = dz2 + (size_t)B * C; float* dpool = dh + (size_t)B * Cr;
+  const size_t shm = ((size_t)256 * VEC + C + Cr) * 4;
+  DT(hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, dim3(B), dim3(256), shm, st, (const float*)dout, (const float*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr),
+     hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr));
+  const size_t nvec = (size_t)B * HW * C / VEC;
+  DT(hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)dout, scale, dpool, (float*)dx, nvec, HW, C),
+     hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)dout, scale, dpool, (bf16_t*)dx, nvec, HW, C));
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 255) / 256), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+
+int vqa_spatial_fwd(int dtype, const void* x, const float* w, float* pooled2, int* amax, float* amap, void* out, int B, int H, int W, int C, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  if (C % VEC) return VQA_EARG;
+  const size_t npix = (size_t)B * H * W;
+  const int pg = (int)((npix + 3) / 4 > 8192 ? 8192 : (npix + 3) / 4);
+  DT(hipLaunchKernelGGL(spatial_pool_kernel<float>, dim3(pg), dim3(256), 0, st, (const float*)x, pooled2, amax, npix, C),
+     hipLaunchKernelGGL(spatial_pool_kernel<bf16_t>, dim3(pg), dim3(256), 0, st, (const bf16_t*)x, pooled2, amax, npix, C));
+  hipLaunchKernelGGL(spatial_conv_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, pooled2, w, amap, B, H, W);
+  const size_t nvec = npix * C / VEC;
+  DT(hipLaunchKernelGGL(scale_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, (const float*)nullptr, amap, (float*)out, nvec, H * W, C),
+     hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x, (const float*)nullptr, amap, (bf16_t*)out, nvec, H * W, C));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+// scratch: dpre[B*H*W] | dpool2[B*H*W*2] floats
+int vqa_spatial_bwd(int dtype, const void* dout, const void* x, const float* w, const float* pooled2, const int* amax, const float* amap,
+                    float* scratch, void* dx, float* dw, int B, int H, int W, int C, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  if (C % VEC) return VQA_EARG;
+  const size_t npix = (size_t)B * H * W;
+  float* dpre = scratch; float* dpool2 = dpre + npix;
+  const int pg = (int)((npix + 3) / 4 > 8192 ? 8192 : (npix + 3) / 4);
+  DT(hipLaunchKernelGGL(spatial_bwd_reduce_kernel<float>, dim3(pg), dim3(256), 0, st, (const float*)dout, (const float*)x, amap, dpre, npix, C),
+     hipLaunchKernelGGL(spatial_bwd_reduce_kernel<bf16_t>, dim3(pg), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, amap, dpre, npix, C));
+  hipLaunchKernelGGL(spatial_bwd_conv_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, dpre, w, dpool2, B, H, W);
+  const size_t nvec = npix * C / VEC;
+  DT(hipLaunchKernelGGL(spatial_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)dout, amap, dpool2, amax, (float*)dx, nvec, C),
+     hipLaunchKernelGGL(spatial_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)dout, amap, dpool2, amax, (bf16_t*)dx, nvec, C));
+  hipLaunchKernelGGL(spatial_wgrad_kernel, dim3(98), dim3(256), 0, st, dpre, pooled2, dw, B, H, W);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+
+int vqa_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int HW, int C, hipStream_t st) {
+  const size_t n = (size_t)B * HW * C;
+  DT(hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)in, out, B, HW, C),
+     hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)in, out, B, HW, C));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int HW, int C, hipStream_t st) {
+  const size_t n = (size_t)B * HW * C;
+  DT(hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, (float*)out, B, HW, C),
+     hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, (bf16_t*)out, B, HW, C));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) VQA kernels.  Wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VQA_OK 0
+#define VQA_EARG 1000   // argument / shape error (never launches)
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // RNE, NaN stays NaN (v_cvt_pk_bf16_f32)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// 16-byte vector of T (4 floats or 8 bf16) with element access as float.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  u32x4 raw;
+  __device__ __forceinline__ float get(int i) const { return __uint_as_float(raw[i]); }
+  __device__ __forceinline__ void set(int i, float v) { raw[i] = __float_as_uint(v); }
+};
+template <> struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  u32x4 raw;
+  __device__ __forceinline__ float get(int i) const {
+    uint32_t w = raw[i >> 1];
+    return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+  }
+  __device__ __forceinline__ void set(int i, float v) {
+    uint32_t b = f2bf(v);
+    uint32_t w = raw[i >> 1];
+    raw[i >> 1] = (i & 1) ? ((w & 0x0000ffffu) | (b << 16)) : ((w & 0xffff0000u) | b);
+  }
+};
+template <typename T> __device__ __forceinline__ Vec16<T> ldg16(const T* p) {
+  Vec16<T> v; v.raw = *reinterpret_cast<const u32x4*>(p); return v;
+}
+template <typename T> __device__ __forceinline__ void stg16(T* p, const Vec16<T>& v) {
+  *reinterpret_cast<u32x4*>(p) = v.raw;
+}
+template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
+  Vec16<T> v; v.raw = u32x4{0u, 0u, 0u, 0u}; return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Counter-based dropout RNG: keep(seed, idx) is a pure function so backward regenerates the mask.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
+  uint32_t h = mix32((uint32_t)idx ^ mix32((uint32_t)(idx >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9E3779B9u);
+  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+#define VQA_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

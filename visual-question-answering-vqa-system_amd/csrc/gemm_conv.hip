@@ -1,0 +1,584 @@
+// Implicit-GEMM convolution / linear kernels for gfx950 (MI355X), MFMA 16x16 tiles, 64-lane waves.
+//
+//   igemm_kernel  : out[M][N] = gather(A)[M][K] * W[N][K]^T  (+bias, relu, +addend*(mask>0), BN partial stats)
+//                   - forward conv over NHWC activations (models/cnn_backbone.py:182-195 conv1/conv2, :243-247 shortcut)
+//                   - data-gradient of the same convs (transposed gather)
+//                   - every nn.Linear of the token side as a 1x1 "conv" (models/text_encoder.py:219-221,320-324 ...)
+//                   - the 7x7/2 stem conv straight from the NCHW fp32 image (models/cnn_backbone.py:349-350)
+//   wgrad_kernel  : dW[N][K] += dY[M][N]^T * gather(A)[M][K]   (split over M, fp32 atomics)
+//
+// T = float  -> v_mfma_f32_16x16x4_f32  (exact fp32 fma chain; parity path)
+// T = bf16   -> v_mfma_f32_16x16x32_bf16 (fp32 accumulate; throughput path)
+// LDS tiles hold 128 bytes of K per row (+16 B pad): [row][k] for igemm, [k][row] for wgrad
+// (wgrad reads its operands with ds_read_b64_tr_b16 so the contraction index ends up lane-contiguous).
+#include "common.h"
+
+enum { LOADER_NHWC = 0, LOADER_STEM = 1 };
+
+struct IGemmParams {
+  const void* a; const void* w; void* out;
+  const float* bias; const void* addend; const void* addmask; float* stats;
+  int M, N, Kp, Kw;          // Kp: reduction length rounded up to BK; Kw: weight row length (elements)
+  int B, H, W, C;            // source tensor (NHWC; NCHW fp32 image for the stem loader)
+  int Ho, Wo;                // spatial dims of the GEMM rows (M = B*Ho*Wo)
+  int R, S, stride, pad, transposed, relu;
+  float drop_p; unsigned long long drop_seed;   // dropout applied after bias/relu, before the addend
+};
+
+template <typename T> struct GT;
+template <> struct GT<float>  { static constexpr int VEC = 4, BK = 32, MK = 4; };
+template <> struct GT<bf16_t> { static constexpr int VEC = 8, BK = 64, MK = 32; };
+
+struct RowInfo { int pix, ih0, iw0; };
+
+__device__ __forceinline__ RowInfo decode_row(int m, int M, int HoWo, int Wo, int HW, int stride, int pad, int transposed, bool stem) {
+  RowInfo ri;
+  if (m >= M) { ri.pix = -1; ri.ih0 = 0; ri.iw0 = 0; return ri; }
+  int b = m / HoWo, rem = m - b * HoWo;
+  int oh = rem / Wo, ow = rem - oh * Wo;
+  ri.pix = stem ? b : b * HW;
+  if (!transposed) { ri.ih0 = oh * stride - pad; ri.iw0 = ow * stride - pad; }
+  else { ri.ih0 = oh + pad; ri.iw0 = ow + pad; }
+  return ri;
+}
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> load_a_nhwc(const T* a, const RowInfo& ri, int r, int s, int c,
+                                                int H, int W, int C, int stride, int transposed) {
+  bool ok = ri.pix >= 0 && c < C;
+  int ih, iw;
+  if (!transposed) { ih = ri.ih0 + r; iw = ri.iw0 + s; }
+  else {
+    int th = ri.ih0 - r, tw = ri.iw0 - s;
+    ok = ok && th >= 0 && tw >= 0;
+    ih = th / stride; iw = tw / stride;
+    ok = ok && (ih * stride == th) && (iw * stride == tw);
+  }
+  ok = ok && ih >= 0 && ih < H && iw >= 0 && iw < W;
+  if (!ok) return zero16<T>();
+  return ldg16(a + ((size_t)(ri.pix + ih * W + iw)) * C + c);
+}
+
+// stem: k = (r*7 + s)*3 + c over the NCHW fp32 image; ri.pix = batch index
+template <typename T>
+__device__ __forceinline__ Vec16<T> load_a_stem(const float* img, const RowInfo& ri, int k0, int H, int W, int Kreal) {
+  Vec16<T> v = zero16<T>();
+  if (ri.pix < 0) return v;
+#pragma unroll
+  for (int j = 0; j < Vec16<T>::N; ++j) {
+    int k = k0 + j;
+    if (k < Kreal) {
+      int tap = k / 3, c = k - tap * 3;
+      int r = tap / 7, s = tap - r * 7;
+      int ih = ri.ih0 + r, iw = ri.iw0 + s;
+      if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+        v.set(j, img[((size_t)(ri.pix * 3 + c) * H + ih) * W + iw]);
+    }
+  }
+  return v;
+}
+
+template <typename T, int BM, int BN> struct IGemmCfg {
+  static constexpr int LD = GT<T>::BK + GT<T>::VEC;
+  static constexpr int SMEM = 2 * (BM + BN) * LD * (int)sizeof(T);
+};
+
+template <typename T, int BM, int BN, int LOADER>
+__global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
+  using G = GT<T>;
+  constexpr int VEC = G::VEC, BK = G::BK, LD = BK + VEC;
+  constexpr int WN = BN / 64, WM = 4 / WN, TM = BM / WM, MT = TM / 16, NT = 4;
+  constexpr int AV = BM / 32, BV = BN / 32;
+  constexpr int SMEM = IGemmCfg<T, BM, BN>::SMEM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* As = reinterpret_cast<T*>(smem);
+  T* Bs = As + 2 * BM * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int vec = tid & 7, rbase = tid >> 3;
+  const T* aT = reinterpret_cast<const T*>(p.a);
+  const float* aImg = reinterpret_cast<const float*>(p.a);
+  const T* wT = reinterpret_cast<const T*>(p.w);
+
+  RowInfo ri[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i)
+    ri[i] = decode_row(m0 + rbase + 32 * i, p.M, p.Ho * p.Wo, p.Wo, p.H * p.W, p.stride, p.pad, p.transposed, LOADER == LOADER_STEM);
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Vec16<T> ra[AV], rb[BV];
+  const int nk = p.Kp / BK;
+  const int taps = p.R * p.S;
+
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+    if (LOADER == LOADER_NHWC) {
+      int tap = 0, c0 = k0;
+      if (taps > 1) { tap = k0 / p.C; c0 = k0 - tap * p.C; }
+      const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+      for (int i = 0; i < AV; ++i)
+        ra[i] = load_a_nhwc<T>(aT, ri[i], r, s, c0 + vec * VEC, p.H, p.W, p.C, p.stride, p.transposed);
+    } else {
+#pragma unroll
+      for (int i = 0; i < AV; ++i)
+        ra[i] = load_a_stem<T>(aImg, ri[i], k0 + vec * VEC, p.H, p.W, 147);
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int n = n0 + rbase + 32 * i, k = k0 + vec * VEC;
+      rb[i] = (n < p.N && k < p.Kw) ? ldg16(wT + (size_t)n * p.Kw + k) : zero16<T>();
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AV; ++i)
+      *reinterpret_cast<u32x4*>(&As[(buf * BM + rbase + 32 * i) * LD + vec * VEC]) = ra[i].raw;
+#pragma unroll
+    for (int i = 0; i < BV; ++i)
+      *reinterpret_cast<u32x4*>(&Bs[(buf * BN + rbase + 32 * i) * LD + vec * VEC]) = rb[i].raw;
+  };
+  auto compute = [&](int buf) {
+    const T* Ab = As + (buf * BM + wm * TM + (lane & 15)) * LD;
+    const T* Bb = Bs + (buf * BN + wn * 64 + (lane & 15)) * LD;
+#pragma unroll
+    for (int kk = 0; kk < BK / G::MK; ++kk) {
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 af[MT], bfv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 16 * LD + kk * 32 + (lane >> 4) * 8);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bfv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 16 * LD + kk * 32 + (lane >> 4) * 8);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
+      } else {
+        float af[MT], bfv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = Ab[i * 16 * LD + kk * 4 + (lane >> 4)];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bfv[j] = Bb[j * 16 * LD + kk * 4 + (lane >> 4)];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kt + 1);
+    compute(kt & 1);
+    if (kt + 1 < nk) sstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias / relu in registers -------------------------------------------------
+  if (p.bias || p.relu) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+      const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][j][r] + bv;
+          acc[i][j][r] = p.relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+  }
+  if (p.drop_p > 0.f) {
+    const float ks = 1.f / (1.f - p.drop_p);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t m = (size_t)(m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r);
+          const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+          acc[i][j][r] = drop_keep(p.drop_seed, m * p.N + n, p.drop_p) ? acc[i][j][r] * ks : 0.f;
+        }
+  }
+  // ---- BatchNorm partial statistics (sum, sum of squares per output channel of this M tile) ----
+  float* red = reinterpret_cast<float*>(smem + SMEM - 4096);   // [WM][BN][2]
+  if (p.stats) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float v = acc[i][j][r]; s += v; q += v * v; }
+      s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+      if (lane < 16) {
+        red[(wm * BN + wn * 64 + j * 16 + lane) * 2 + 0] = s;
+        red[(wm * BN + wn * 64 + j * 16 + lane) * 2 + 1] = q;
+      }
+    }
+  }
+  // ---- stage C through LDS so global stores are full 16-byte row segments ---------------------
+  constexpr int LDC = BN + VEC;
+  T* Cs = reinterpret_cast<T*>(smem);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cs[(wm * TM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * 64 + j * 16 + (lane & 15)] = from_f<T>(acc[i][j][r]);
+  __syncthreads();
+  if (p.stats && tid < BN) {
+    const int n = n0 + tid;
+    if (n < p.N) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+      p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = s;
+      p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = q;
+    }
+  }
+  constexpr int VR = BN / VEC, RP = 256 / VR;
+  T* outT = reinterpret_cast<T*>(p.out);
+  const T* addT = reinterpret_cast<const T*>(p.addend);
+  const T* mskT = reinterpret_cast<const T*>(p.addmask);
+  const bool vec_ok = (p.N % VEC) == 0;
+  for (int row = tid / VR; row < BM; row += RP) {
+    const int m = m0 + row, n = n0 + (tid % VR) * VEC;
+    if (m >= p.M || n >= p.N) continue;
+    Vec16<T> v; v.raw = *reinterpret_cast<const u32x4*>(&Cs[row * LDC + (tid % VR) * VEC]);
+    const size_t off = (size_t)m * p.N + n;
+    if (vec_ok) {
+      if (addT) {
+        Vec16<T> av = ldg16(addT + off);
+        if (mskT) {
+          Vec16<T> mv = ldg16(mskT + off);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + (mv.get(j) > 0.f ? av.get(j) : 0.f));
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + av.get(j));
+        }
+      }
+      stg16(outT + off, v);
+    } else {
+      for (int j = 0; j < VEC && n + j < p.N; ++j) {
+        float x = v.get(j);
+        if (addT) { float a = to_f<T>(addT[off + j]); x += (!mskT || to_f<T>(mskT[off + j]) > 0.f) ? a : 0.f; }
+        outT[off + j] = from_f<T>(x);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+  const void* dy; const void* x; float* dw;
+  int M, N, Kw;              // dy [M][N]; dw [N][Kw] fp32 (+=)
+  int B, H, W, C, Ho, Wo, R, S, stride, pad, chunk;
+};
+
+template <typename T, int BMW, int BNW, int LOADER>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  using G = GT<T>;
+  constexpr int VEC = G::VEC, BKM = 32;
+  constexpr int LDY = BMW + VEC, LDX = BNW + VEC;
+  constexpr int TMW = BMW / 2, TNW = BNW / 2, MT = TMW / 16, NT = TNW / 16;
+  constexpr int VRY = BMW / VEC, VRX = BNW / VEC;
+  constexpr int YV = BKM * VRY / 256, XV = BKM * VRX / 256;
+  static_assert(YV >= 1 && XV >= 1, "tile too small");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* Ys = reinterpret_cast<T*>(smem);          // [2][BKM][LDY]
+  T* Xs = Ys + 2 * BKM * LDY;                  // [2][BKM][LDX]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_k = (p.Kw + BNW - 1) / BNW;
+  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+  const int n0 = tile_n * BMW, k20 = tile_k * BNW;
+  const int mbeg = blockIdx.y * p.chunk, mend = min(p.M, mbeg + p.chunk);
+  if (mbeg >= mend) return;
+  const T* dyT = reinterpret_cast<const T*>(p.dy);
+  const T* xT = reinterpret_cast<const T*>(p.x);
+  const float* xImg = reinterpret_cast<const float*>(p.x);
+  const int taps = p.R * p.S;
+  int tap = 0, c0 = k20;
+  if (LOADER == LOADER_NHWC && taps > 1) { tap = k20 / p.C; c0 = k20 - tap * p.C; }
+  const int tr = tap / p.S, ts = tap - tr * p.S;
+  const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Vec16<T> ry[YV], rx[XV];
+
+  auto gload = [&](int ms) {
+#pragma unroll
+    for (int i = 0; i < YV; ++i) {
+      const int idx = tid + 256 * i, row = idx / VRY, v = idx - row * VRY;
+      const int m = ms + row, n = n0 + v * VEC;
+      ry[i] = (m < mend && n < p.N) ? ldg16(dyT + (size_t)m * p.N + n) : zero16<T>();
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int idx = tid + 256 * i, row = idx / VRX, v = idx - row * VRX;
+      const int m = ms + row;
+      RowInfo ri = decode_row(m, mend, HoWo, p.Wo, HW, p.stride, p.pad, 0, LOADER == LOADER_STEM);
+      if (LOADER == LOADER_NHWC) rx[i] = load_a_nhwc<T>(xT, ri, tr, ts, c0 + v * VEC, p.H, p.W, p.C, p.stride, 0);
+      else rx[i] = load_a_stem<T>(xImg, ri, k20 + v * VEC, p.H, p.W, p.Kw);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < YV; ++i) {
+      const int idx = tid + 256 * i, row = idx / VRY, v = idx - row * VRY;
+      *reinterpret_cast<u32x4*>(&Ys[(buf * BKM + row) * LDY + v * VEC]) = ry[i].raw;
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int idx = tid + 256 * i, row = idx / VRX, v = idx - row * VRX;
+      *reinterpret_cast<u32x4*>(&Xs[(buf * BKM + row) * LDX + v * VEC]) = rx[i].raw;
+    }
+  };
+  auto compute = [&](int buf) {
+    const int g = lane >> 4, li = lane & 15;
+    if constexpr (sizeof(T) == 2) {
+      // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block and
+      // receives column (lane&15) of the four rows -> two reads give the 8 contraction values of one MFMA operand.
+      const int q = li >> 2, pp = li & 3;
+      const T* yb = Ys + (buf * BKM + 8 * g + q) * LDY + wm * TMW + 4 * pp;
+      const T* xb = Xs + (buf * BKM + 8 * g + q) * LDX + wn * TNW + 4 * pp;
+      bf16x8 af[MT], bfv[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + i * 16));
+        i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + 4 * LDY + i * 16));
+        typedef __attribute__((ext_vector_type(8))) short i16x8;
+        i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[i] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + j * 16));
+        i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + 4 * LDX + j * 16));
+        typedef __attribute__((ext_vector_type(8))) short i16x8;
+        i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bfv[j] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BKM / 4; ++kk) {
+        float af[MT], bfv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = Ys[(buf * BKM + kk * 4 + g) * LDY + wm * TMW + i * 16 + li];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bfv[j] = Xs[(buf * BKM + kk * 4 + g) * LDX + wn * TNW + j * 16 + li];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nsteps = (mend - mbeg + BKM - 1) / BKM;
+  gload(mbeg);
+  sstore(0);
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) gload(mbeg + (st + 1) * BKM);
+    compute(st & 1);
+    if (st + 1 < nsteps) sstore((st + 1) & 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wm * TMW + i * 16 + (lane >> 4) * 4 + r;
+        const int k2 = k20 + wn * TNW + j * 16 + (lane & 15);
+        if (n < p.N && k2 < p.Kw) atomicAdd(p.dw + (size_t)n * p.Kw + k2, acc[i][j][r]);
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: cast (+row pad) and [N][T][C] -> [C][T][N] transpose for the data-gradient GEMM
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_rows_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int K, int Kp) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * Kp) return;
+  int n = (int)(i / Kp), k = (int)(i - (size_t)n * Kp);
+  out[i] = from_f<T>(k < K ? in[(size_t)n * K + k] : 0.f);
+}
+template <typename T>
+__global__ void pack_transpose_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int TT, int C) {
+  // out[c][t][n] = in[n][t][c]
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * TT * C) return;
+  int n = (int)(i % N); size_t r = i / N; int t = (int)(r % TT); int c = (int)(r / TT);
+  out[i] = from_f<T>(in[((size_t)n * TT + t) * C + c]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int LOADER>
+static int launch_igemm(const IGemmParams& p, hipStream_t st) {
+  constexpr int SMEM = IGemmCfg<T, BM, BN>::SMEM;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER>), dim3(tiles), dim3(256), SMEM, st, p);
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
+}
+
+static void igemm_tile(int M, int N, int* bm, int* bn) {
+  if (N <= 64) { *bn = 64; *bm = 128; }
+  else { *bn = 128; *bm = 128; }
+  long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
+  if (tiles < 384) { *bm = 64; *bn = 64; }
+}
+
+template <typename T>
+static int igemm_dispatch(const IGemmParams& p, int loader, hipStream_t st) {
+  int bm, bn; igemm_tile(p.M, p.N, &bm, &bn);
+  if (loader == LOADER_STEM) return launch_igemm<T, 128, 64, LOADER_STEM>(p, st);
+  if (bm == 128 && bn == 128) return launch_igemm<T, 128, 128, LOADER_NHWC>(p, st);
+  if (bm == 128 && bn == 64) return launch_igemm<T, 128, 64, LOADER_NHWC>(p, st);
+  return launch_igemm<T, 64, 64, LOADER_NHWC>(p, st);
+}
+
+template <typename T, int BMW, int BNW, int LOADER>
+static int launch_wgrad(const WgradParams& p, int nsplit, hipStream_t st) {
+  constexpr int VEC = GT<T>::VEC;
+  constexpr int SMEM = 2 * 32 * (BMW + VEC + BNW + VEC) * (int)sizeof(T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BMW, BNW, LOADER>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  const int tiles = ((p.N + BMW - 1) / BMW) * ((p.Kw + BNW - 1) / BNW);
+  hipLaunchKernelGGL((wgrad_kernel<T, BMW, BNW, LOADER>), dim3(tiles, nsplit), dim3(256), SMEM, st, p);
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
+}
+
+extern "C" {
+
+// number of M tiles igemm will use (= rows of the BN partial-statistics slab [tiles][2][N])
+int vqa_igemm_mtiles(int M, int N, int loader) {
+  int bm, bn; igemm_tile(M, N, &bm, &bn);
+  if (loader == LOADER_STEM) bm = 128;
+  return (M + bm - 1) / bm;
+}
+
+int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, const float* bias,
+              const void* addend, const void* addmask, float* stats,
+              int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
+              int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
+              hipStream_t st) {
+  if (M <= 0 || N <= 0 || !a || !w || !out) return VQA_EARG;
+  const int VEC = dtype ? 8 : 4, BK = dtype ? 64 : 32;
+  if (loader == LOADER_NHWC) {
+    if (C % VEC) return VQA_EARG;
+    if (R * S > 1 && (C % BK)) return VQA_EARG;
+    if (Kw != R * S * C) return VQA_EARG;
+  } else {
+    if (Kw % BK || N != 64 || C != 3 || R != 7 || S != 7) return VQA_EARG;
+  }
+  if ((long)M != (long)B * Ho * Wo) return VQA_EARG;
+  IGemmParams p;
+  p.a = a; p.w = w; p.out = out; p.bias = bias; p.addend = addend; p.addmask = addmask; p.stats = stats;
+  p.M = M; p.N = N; p.Kw = Kw; p.Kp = (Kw + BK - 1) / BK * BK;
+  p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.transposed = transposed; p.relu = relu; p.drop_p = drop_p; p.drop_seed = drop_seed;
+  return dtype ? igemm_dispatch<bf16_t>(p, loader, st) : igemm_dispatch<float>(p, loader, st);
+}
+
+int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
+              int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
+              int R, int S, int stride, int pad, hipStream_t st) {
+  if (M <= 0 || N <= 0 || !dy || !x || !dw) return VQA_EARG;
+  const int VEC = dtype ? 8 : 4;
+  if (N % VEC) return VQA_EARG;
+  if (loader == LOADER_NHWC) {
+    if (C % VEC || Kw != R * S * C) return VQA_EARG;
+  } else if (Kw != 147) return VQA_EARG;
+  if ((long)M != (long)B * Ho * Wo) return VQA_EARG;
+  WgradParams p;
+  p.dy = dy; p.x = x; p.dw = dw; p.M = M; p.N = N; p.Kw = Kw; p.B = B; p.H = H; p.W = W; p.C = C;
+  p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  // tile: 128x128 when both dims allow it and (for multi-tap convs) a tile stays inside one tap
+  const bool big = (N >= 128) && (R * S > 1 ? (C % 128 == 0) : (Kw >= 128));
+  const int bmw = big ? 128 : 64, bnw = big ? 128 : 64;
+  if (loader == LOADER_NHWC && R * S > 1 && (C % bnw)) return VQA_EARG;
+  const long tiles = (long)((N + bmw - 1) / bmw) * ((Kw + bnw - 1) / bnw);
+  long nsplit = (2048 + tiles - 1) / tiles;                 // aim for ~2048 workgroups
+  long maxsplit = (M + 255) / 256;                           // at least 256 rows per split
+  if (nsplit > maxsplit) nsplit = maxsplit;
+  if (nsplit < 1) nsplit = 1;
+  int chunk = (int)((M + nsplit - 1) / nsplit);
+  chunk = (chunk + 31) / 32 * 32;
+  nsplit = (M + chunk - 1) / chunk;
+  p.chunk = chunk;
+  if (loader == LOADER_STEM)
+    return dtype ? launch_wgrad<bf16_t, 64, 64, LOADER_STEM>(p, (int)nsplit, st) : launch_wgrad<float, 64, 64, LOADER_STEM>(p, (int)nsplit, st);
+  if (big)
+    return dtype ? launch_wgrad<bf16_t, 128, 128, LOADER_NHWC>(p, (int)nsplit, st) : launch_wgrad<float, 128, 128, LOADER_NHWC>(p, (int)nsplit, st);
+  return dtype ? launch_wgrad<bf16_t, 64, 64, LOADER_NHWC>(p, (int)nsplit, st) : launch_wgrad<float, 64, 64, LOADER_NHWC>(p, (int)nsplit, st);
+}
+
+// out[N][Kp] (T) = cast(in[N][K] fp32), zero padded rows
+int vqa_pack_rows(int dtype, const float* in, void* out, int N, int K, int Kp, hipStream_t st) {
+  if (!in || !out || N <= 0 || K <= 0 || Kp < K) return VQA_EARG;
+  size_t total = (size_t)N * Kp;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype) hipLaunchKernelGGL(pack_rows_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, N, K, Kp);
+  else hipLaunchKernelGGL(pack_rows_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, N, K, Kp);
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
+}
+// out[C][T][N] (T) = in[N][T][C] fp32
+int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int TT, int C, hipStream_t st) {
+  if (!in || !out || N <= 0 || TT <= 0 || C <= 0) return VQA_EARG;
+  size_t total = (size_t)N * TT * C;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype) hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, N, TT, C);
+  else hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, N, TT, C);
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,498 @@
+// Token-side kernels for gfx950: embedding+positional encoding, LayerNorm, multi-head attention
+// (self: keys masked with -inf, cross: unmasked), masked mean-pool, sigmoid gate, bias/ReLU/dropout
+// backward, cross-entropy, and the fused optimizer tail (global L2 norm, clip, AdamW).
+//   embedding*sqrt(d)+pe      models/text_encoder.py:504-510, :112-114
+//   LayerNorm                 models/text_encoder.py:390,395,519 ; cross_attention.py:286-287,295 ; fusion.py:326
+//   attention                 models/text_encoder.py:237-258 ; models/cross_attention.py:176-198
+//   masked mean / gate        models/fusion.py:303-320, :160-166
+//   CE / clip / AdamW         training/train.py:120, :204-208, :127-132
+// Rows are tokens ([B*L][D], D contiguous).  One 64-lane wave owns one row / one (batch, head).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_fwd_kernel(const long long* __restrict__ ids, const float* __restrict__ emb, const float* __restrict__ pe,
+                                 T* __restrict__ out, int rows, int L, int D, int V, float scale, float p, uint64_t seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * D) return;
+  const int d = (int)(i % D), row = (int)(i / D), l = row % L;
+  long long id = ids[row];
+  float v = (id >= 0 && id < V) ? emb[(size_t)id * D + d] * scale : 0.f;
+  v += pe[(size_t)l * D + d];
+  if (p > 0.f) v = drop_keep(seed, i, p) ? v / (1.f - p) : 0.f;
+  out[i] = from_f<T>(v);
+}
+template <typename T>
+__global__ void embed_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ dout, float* demb,
+                                 int rows, int D, int V, float scale, float p, uint64_t seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * D) return;
+  const int d = (int)(i % D), row = (int)(i / D);
+  const long long id = ids[row];
+  if (id <= 0 || id >= V) return;                       // padding_idx = 0 receives no gradient
+  float g = to_f<T>(dout[i]) * scale;
+  if (p > 0.f) g = drop_keep(seed, i, p) ? g / (1.f - p) : 0.f;
+  atomicAdd(demb + (size_t)id * D + d, g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: y = (x-mean)*rstd*gamma+beta ; optional dropout ; optional + addrow[row % period]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            T* __restrict__ out, float* __restrict__ stats, int rows, int D, float eps,
+                                                            float p, uint64_t seed, const float* __restrict__ addrow, int period) {
+  const int lane = threadIdx.x & 63;
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  for (int row = wid; row < rows; row += nw) {
+    const T* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += to_f<T>(xr[c]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) { const float t = to_f<T>(xr[c]) - mean; q += t * t; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0 && stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    for (int c = lane; c < D; c += 64) {
+      float y = (to_f<T>(xr[c]) - mean) * rstd * gamma[c] + beta[c];
+      if (p > 0.f) y = drop_keep(seed, (uint64_t)row * D + c, p) ? y / (1.f - p) : 0.f;
+      if (addrow) y += addrow[(size_t)(row % period) * D + c];
+      out[(size_t)row * D + c] = from_f<T>(y);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ stats, const T* __restrict__ addend, T* __restrict__ dx,
+                                                            float* dgamma, float* dbeta, int rows, int D, float p, uint64_t seed,
+                                                            float* dadd, int period) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  float ag[8], ab[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) ag[t] = ab[t] = 0.f;
+  for (int row = wid; row < rows; row += nw) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float gv[8], xh[8];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int c = lane + 64 * t;
+      gv[t] = 0.f; xh[t] = 0.f;
+      if (c < D) {
+        const size_t o = (size_t)row * D + c;
+        float g = to_f<T>(dout[o]);
+        if (dadd) atomicAdd(dadd + (size_t)(row % period) * D + c, g);
+        if (p > 0.f) g = drop_keep(seed, o, p) ? g / (1.f - p) : 0.f;
+        const float h = (to_f<T>(x[o]) - mean) * rstd;
+        gv[t] = g; xh[t] = h;
+        ag[t] += g * h; ab[t] += g;
+        const float gy = g * gamma[c];
+        m1 += gy; m2 += gy * h;
+      }
+    }
+    m1 = wave_sum(m1) / (float)D; m2 = wave_sum(m2) / (float)D;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int c = lane + 64 * t;
+      if (c < D) {
+        const size_t o = (size_t)row * D + c;
+        float r = rstd * (gv[t] * gamma[c] - m1 - xh[t] * m2);
+        if (addend) r += to_f<T>(addend[o]);
+        dx[o] = from_f<T>(r);
+      }
+    }
+  }
+  __shared__ float sh[2][4][512];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { sh[0][wave][lane + 64 * t] = ag[t]; sh[1][wave][lane + 64 * t] = ab[t]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(dgamma + c, sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c]);
+    atomicAdd(dbeta + c, sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention, one wave per (batch, head).  q/k/v/ctx are token-major with row strides ld* (elements);
+// head h occupies columns [h*hd, (h+1)*hd).  probs [B][H][Lq][Lk] fp32 holds softmax BEFORE dropout.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                      int ldq, int ldk, int ldv, const float* __restrict__ kmask, float* __restrict__ probs,
+                                                      T* __restrict__ ctx, int ldc, int H, int Lq, int Lk, int hd, float scale, float p, uint64_t seed) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H, lane = threadIdx.x, ldh = hd + 1, ldp = Lk + 1;
+  float* Qs = sm; float* Ks = Qs + Lq * ldh; float* Vs = Ks + Lk * ldh; float* Ps = Vs + Lk * ldh;
+  for (int i = lane; i < Lq * hd; i += 64) { const int r = i / hd, d = i - r * hd; Qs[r * ldh + d] = to_f<T>(q[(size_t)(b * Lq + r) * ldq + h * hd + d]); }
+  for (int i = lane; i < Lk * hd; i += 64) {
+    const int r = i / hd, d = i - r * hd;
+    Ks[r * ldh + d] = to_f<T>(k[(size_t)(b * Lk + r) * ldk + h * hd + d]);
+    Vs[r * ldh + d] = to_f<T>(v[(size_t)(b * Lk + r) * ldv + h * hd + d]);
+  }
+  __syncthreads();
+  for (int i = lane; i < Lq * Lk; i += 64) {
+    const int r = i / Lk, c = i - r * Lk;
+    float s = 0.f;
+    for (int d = 0; d < hd; ++d) s += Qs[r * ldh + d] * Ks[c * ldh + d];
+    s = s / scale;                                                  // divide by sqrt(hd) before masking
+    if (kmask && kmask[b * Lk + c] == 0.f) s = -INFINITY;
+    Ps[r * ldp + c] = s;
+  }
+  __syncthreads();
+  float* pg = probs + ((size_t)(b * H + h) * Lq) * Lk;
+  for (int r = 0; r < Lq; ++r) {
+    float m = -INFINITY;
+    for (int c = lane; c < Lk; c += 64) m = fmaxf(m, Ps[r * ldp + c]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < Lk; c += 64) { const float e = expf(Ps[r * ldp + c] - m); Ps[r * ldp + c] = e; sum += e; }   // all -inf row -> NaN like torch
+    sum = wave_sum(sum);
+    for (int c = lane; c < Lk; c += 64) {
+      float pr = Ps[r * ldp + c] / sum;
+      pg[(size_t)r * Lk + c] = pr;
+      if (p > 0.f) pr = drop_keep(seed, ((size_t)(b * H + h) * Lq + r) * Lk + c, p) ? pr / (1.f - p) : 0.f;
+      Ps[r * ldp + c] = pr;
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < Lq * hd; i += 64) {
+    const int r = i / hd, d = i - r * hd;
+    float a = 0.f;
+    for (int c = 0; c < Lk; ++c) a += Ps[r * ldp + c] * Vs[c * ldh + d];
+    ctx[(size_t)(b * Lq + r) * ldc + h * hd + d] = from_f<T>(a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const T* __restrict__ dctx, int ldc, const T* __restrict__ q, const T* __restrict__ k,
+                                                      const T* __restrict__ v, int ldq, int ldk, int ldv, const float* __restrict__ probs,
+                                                      T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, int lddq, int lddk, int lddv,
+                                                      int H, int Lq, int Lk, int hd, float scale, float p, uint64_t seed) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H, lane = threadIdx.x, ldh = hd + 1, ldp = Lk + 1;
+  float* Qs = sm; float* Os = Qs + Lq * ldh; float* Ks = Os + Lq * ldh; float* Vs = Ks + Lk * ldh;
+  float* Ps = Vs + Lk * ldh; float* Ds = Ps + Lq * ldp;             // Ps: dropped probs, Ds: dS
+  for (int i = lane; i < Lq * hd; i += 64) {
+    const int r = i / hd, d = i - r * hd;
+    Qs[r * ldh + d] = to_f<T>(q[(size_t)(b * Lq + r) * ldq + h * hd + d]);
+    Os[r * ldh + d] = to_f<T>(dctx[(size_t)(b * Lq + r) * ldc + h * hd + d]);
+  }
+  for (int i = lane; i < Lk * hd; i += 64) {
+    const int r = i / hd, d = i - r * hd;
+    Ks[r * ldh + d] = to_f<T>(k[(size_t)(b * Lk + r) * ldk + h * hd + d]);
+    Vs[r * ldh + d] = to_f<T>(v[(size_t)(b * Lk + r) * ldv + h * hd + d]);
+  }
+  __syncthreads();
+  const float* pg = probs + ((size_t)(b * H + h) * Lq) * Lk;
+  for (int r = 0; r < Lq; ++r) {
+    float t = 0.f;
+    for (int c = lane; c < Lk; c += 64) {
+      const float pr = pg[(size_t)r * Lk + c];
+      float ks = 1.f;
+      if (p > 0.f) ks = drop_keep(seed, ((size_t)(b * H + h) * Lq + r) * Lk + c, p) ? 1.f / (1.f - p) : 0.f;
+      float dpd = 0.f;
+      for (int d = 0; d < hd; ++d) dpd += Os[r * ldh + d] * Vs[c * ldh + d];
+      const float dp = dpd * ks;
+      Ps[r * ldp + c] = pr * ks;
+      Ds[r * ldp + c] = dp;
+      t += dp * pr;
+    }
+    t = wave_sum(t);
+    for (int c = lane; c < Lk; c += 64) Ds[r * ldp + c] = pg[(size_t)r * Lk + c] * (Ds[r * ldp + c] - t) / scale;
+  }
+  __syncthreads();
+  for (int i = lane; i < Lq * hd; i += 64) {
+    const int r = i / hd, d = i - r * hd;
+    float a = 0.f;
+    for (int c = 0; c < Lk; ++c) a += Ds[r * ldp + c] * Ks[c * ldh + d];
+    dq[(size_t)(b * Lq + r) * lddq + h * hd + d] = from_f<T>(a);
+  }
+  for (int i = lane; i < Lk * hd; i += 64) {
+    const int c = i / hd, d = i - c * hd;
+    float a = 0.f, e = 0.f;
+    for (int r = 0; r < Lq; ++r) { a += Ds[r * ldp + c] * Qs[r * ldh + d]; e += Ps[r * ldp + c] * Os[r * ldh + d]; }
+    dk[(size_t)(b * Lk + c) * lddk + h * hd + d] = from_f<T>(a);
+    dv[(size_t)(b * Lk + c) * lddv + h * hd + d] = from_f<T>(e);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// masked mean over L:  out[b][col0+d] = sum_l x[b][l][d]*m[b][l] / max(sum_l m[b][l], 1)   (mask null -> plain mean)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void masked_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mask, T* __restrict__ out, int ldo, int col0, int L, int D) {
+  const int b = blockIdx.x;
+  float cnt = 0.f;
+  for (int l = 0; l < L; ++l) cnt += mask ? mask[b * L + l] : 1.f;
+  cnt = fmaxf(cnt, 1.f);
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += to_f<T>(x[((size_t)b * L + l) * D + d]) * (mask ? mask[b * L + l] : 1.f);
+    out[(size_t)b * ldo + col0 + d] = from_f<T>(s / cnt);
+  }
+}
+// dx[b][l][d] = (addend ? addend : 0) + dpool[b][col0+d]*m[b][l]/cnt
+template <typename T>
+__global__ void masked_pool_bwd_kernel(const T* __restrict__ dpool, int ldo, int col0, const float* __restrict__ mask, const T* __restrict__ addend,
+                                       T* __restrict__ dx, int L, int D) {
+  const int b = blockIdx.x;
+  float cnt = 0.f;
+  for (int l = 0; l < L; ++l) cnt += mask ? mask[b * L + l] : 1.f;
+  cnt = fmaxf(cnt, 1.f);
+  for (int i = threadIdx.x; i < L * D; i += blockDim.x) {
+    const int l = i / D, d = i - l * D;
+    const size_t o = ((size_t)b * L + l) * D + d;
+    float r = to_f<T>(dpool[(size_t)b * ldo + col0 + d]) * (mask ? mask[b * L + l] : 1.f) / cnt;
+    if (addend) r += to_f<T>(addend[o]);
+    dx[o] = from_f<T>(r);
+  }
+}
+
+// gate: g = sigmoid(z); fused = g*att + (1-g)*txt, cat = [att | txt]  (models/fusion.py:160-166)
+template <typename T>
+__global__ void gate_fwd_kernel(const T* __restrict__ z, const T* __restrict__ cat, T* __restrict__ fused, int B, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  const float g = 1.f / (1.f + expf(-to_f<T>(z[i])));
+  const float a = to_f<T>(cat[(size_t)b * 2 * D + d]), t = to_f<T>(cat[(size_t)b * 2 * D + D + d]);
+  fused[i] = from_f<T>(g * a + (1.f - g) * t);
+}
+template <typename T>
+__global__ void gate_bwd_kernel(const T* __restrict__ dfused, const T* __restrict__ z, const T* __restrict__ cat, T* __restrict__ dz,
+                                T* __restrict__ dcat, int B, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  const float g = 1.f / (1.f + expf(-to_f<T>(z[i])));
+  const float a = to_f<T>(cat[(size_t)b * 2 * D + d]), t = to_f<T>(cat[(size_t)b * 2 * D + D + d]);
+  const float df = to_f<T>(dfused[i]);
+  dz[i] = from_f<T>(df * (a - t) * g * (1.f - g));
+  dcat[(size_t)b * 2 * D + d] = from_f<T>(df * g);
+  dcat[(size_t)b * 2 * D + D + d] = from_f<T>(df * (1.f - g));
+}
+
+// out = a + b (either may alias out)
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = from_f<T>(to_f<T>(a[i]) + to_f<T>(b[i]));
+}
+
+// dz = dout * [out>0] * dropout-keep-scale ; dbias[n] += column sums of dz
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ outact, T* __restrict__ dz,
+                                                           float* dbias, int M, int N, int relu_drop, float p, uint64_t seed) {
+  // block handles a strip of 64 columns x rows_per_block rows; thread (r = tid/64, c = tid%64)
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const size_t o = (size_t)r * N + c;
+      float g = to_f<T>(dout[o]);
+      if (outact) { if (!(to_f<T>(outact[o]) > 0.f)) g = 0.f; else if (p > 0.f) g /= (1.f - p); }   // relu(+dropout): out>0 encodes both
+      else if (p > 0.f) g = drop_keep(seed, o, p) ? g / (1.f - p) : 0.f;
+      if (dz) dz[o] = from_f<T>(g);
+      s += g;
+    }
+  __shared__ float sh[4][64];
+  sh[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N && dbias) atomicAdd(dbias + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  (void)relu_drop;
+}
+
+// cross entropy (mean) forward+backward in one pass: wave per row
+template <typename T>
+__global__ void cross_entropy_kernel(const T* __restrict__ logits, const long long* __restrict__ targets, float* loss, T* __restrict__ dlogits,
+                                     float* __restrict__ logits_f32, int B, int N, float gscale) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= B) return;
+  const T* lr = logits + (size_t)row * N;
+  float m = -INFINITY;
+  for (int c = lane; c < N; c += 64) m = fmaxf(m, to_f<T>(lr[c]));
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += expf(to_f<T>(lr[c]) - m);
+  s = wave_sum(s);
+  const int t = (int)targets[row];
+  const float lse = m + logf(s);
+  if (lane == 0 && loss) atomicAdd(loss, (lse - to_f<T>(lr[t])) / (float)B);
+  for (int c = lane; c < N; c += 64) {
+    const float x = to_f<T>(lr[c]);
+    if (logits_f32) logits_f32[(size_t)row * N + c] = x;
+    if (dlogits) dlogits[(size_t)row * N + c] = from_f<T>((expf(x - lse) - (c == t ? 1.f : 0.f)) * gscale / (float)B);
+  }
+}
+
+template <typename TI, typename TO>
+__global__ void convert_kernel(const TI* __restrict__ in, TO* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = from_f<TO>(to_f<TI>(in[i]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer tail over flat fp32 buffers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* out) {
+  float s = 0.f;
+  const size_t nv = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0) for (size_t i = nv * 4 + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
+  __shared__ float sh[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+// clip_grad_norm_(max_norm) + AdamW (decoupled weight decay), torch semantics (training/train.py:204-208,127-132)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, const float* __restrict__ sumsq,
+                             float max_norm, float gscale) {
+  float coef = gscale;
+  if (sumsq && max_norm > 0.f) {
+    const float norm = sqrtf(*sumsq) * gscale;
+    const float c = max_norm / (norm + 1e-6f);
+    if (c < 1.f) coef *= c;
+  }
+  const float step = lr / bc1, rbc2 = 1.f / sqrtf(bc2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gr = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    pi -= step * mi / (sqrtf(vi) * rbc2 + eps);
+    p[i] = pi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+#define DT(call_f, call_b) do { if (dtype) { call_b; } else { call_f; } } while (0)
+static inline unsigned g1(size_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" {
+
+int vqa_embed_fwd(int dtype, const long long* ids, const float* emb, const float* pe, void* out, int rows, int L, int D, int V,
+                  float scale, float p, unsigned long long seed, hipStream_t st) {
+  const size_t n = (size_t)rows * D;
+  DT(hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(g1(n)), dim3(256), 0, st, ids, emb, pe, (float*)out, rows, L, D, V, scale, p, seed),
+     hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(g1(n)), dim3(256), 0, st, ids, emb, pe, (bf16_t*)out, rows, L, D, V, scale, p, seed));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_embed_bwd(int dtype, const long long* ids, const void* dout, float* demb, int rows, int D, int V, float scale, float p,
+                  unsigned long long seed, hipStream_t st) {
+  const size_t n = (size_t)rows * D;
+  DT(hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(g1(n)), dim3(256), 0, st, ids, (const float*)dout, demb, rows, D, V, scale, p, seed),
+     hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(g1(n)), dim3(256), 0, st, ids, (const bf16_t*)dout, demb, rows, D, V, scale, p, seed));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* stats, int rows, int D, float eps,
+                      float p, unsigned long long seed, const float* addrow, int period, hipStream_t st) {
+  if (D > 512 || rows <= 0) return VQA_EARG;
+  const int grid = (rows + 3) / 4 > 2048 ? 2048 : (rows + 3) / 4;
+  DT(hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)out, stats, rows, D, eps, p, seed, addrow, period),
+     hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)out, stats, rows, D, eps, p, seed, addrow, period));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* gamma, const float* stats, const void* addend, void* dx,
+                      float* dgamma, float* dbeta, int rows, int D, float p, unsigned long long seed, float* dadd, int period, hipStream_t st) {
+  if (D > 512 || rows <= 0) return VQA_EARG;
+  const int grid = (rows + 63) / 64 > 1024 ? 1024 : (rows + 63) / 64;
+  DT(hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)x, gamma, stats, (const float*)addend, (float*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period),
+     hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, stats, (const bf16_t*)addend, (bf16_t*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_attention_fwd(int dtype, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const float* kmask, float* probs,
+                      void* ctx, int ldc, int B, int H, int Lq, int Lk, int hd, float p, unsigned long long seed, hipStream_t st) {
+  const size_t shm = ((size_t)(Lq + 2 * Lk) * (hd + 1) + (size_t)Lq * (Lk + 1)) * 4;
+  if (shm > 160 * 1024) return VQA_EARG;
+  const float scale = sqrtf((float)hd);
+  if (dtype) { if (shm > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); }
+  else { if (shm > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); }
+  DT(hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(B * H), dim3(64), shm, st, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, kmask, probs, (float*)ctx, ldc, H, Lq, Lk, hd, scale, p, seed),
+     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(B * H), dim3(64), shm, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, kmask, probs, (bf16_t*)ctx, ldc, H, Lq, Lk, hd, scale, p, seed));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_attention_bwd(int dtype, const void* dctx, int ldc, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
+                      const float* probs, void* dq, void* dk, void* dv, int lddq, int lddk, int lddv,
+                      int B, int H, int Lq, int Lk, int hd, float p, unsigned long long seed, hipStream_t st) {
+  const size_t shm = ((size_t)(2 * Lq + 2 * Lk) * (hd + 1) + (size_t)2 * Lq * (Lk + 1)) * 4;
+  if (shm > 160 * 1024) return VQA_EARG;
+  const float scale = sqrtf((float)hd);
+  if (dtype) { if (shm > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); }
+  else { if (shm > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); }
+  DT(hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B * H), dim3(64), shm, st, (const float*)dctx, ldc, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, probs, (float*)dq, (float*)dk, (float*)dv, lddq, lddk, lddv, H, Lq, Lk, hd, scale, p, seed),
+     hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, dim3(B * H), dim3(64), shm, st, (const bf16_t*)dctx, ldc, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, H, Lq, Lk, hd, scale, p, seed));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_masked_pool_fwd(int dtype, const void* x, const float* mask, void* out, int ldo, int col0, int B, int L, int D, hipStream_t st) {
+  DT(hipLaunchKernelGGL(masked_pool_fwd_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)x, mask, (float*)out, ldo, col0, L, D),
+     hipLaunchKernelGGL(masked_pool_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)x, mask, (bf16_t*)out, ldo, col0, L, D));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_masked_pool_bwd(int dtype, const void* dpool, int ldo, int col0, const float* mask, const void* addend, void* dx, int B, int L, int D, hipStream_t st) {
+  DT(hipLaunchKernelGGL(masked_pool_bwd_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)dpool, ldo, col0, mask, (const float*)addend, (float*)dx, L, D),
+     hipLaunchKernelGGL(masked_pool_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)dpool, ldo, col0, mask, (const bf16_t*)addend, (bf16_t*)dx, L, D));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_gate_fwd(int dtype, const void* z, const void* cat, void* fused, int B, int D, hipStream_t st) {
+  DT(hipLaunchKernelGGL(gate_fwd_kernel<float>, dim3(g1((size_t)B * D)), dim3(256), 0, st, (const float*)z, (const float*)cat, (float*)fused, B, D),
+     hipLaunchKernelGGL(gate_fwd_kernel<bf16_t>, dim3(g1((size_t)B * D)), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)cat, (bf16_t*)fused, B, D));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_gate_bwd(int dtype, const void* dfused, const void* z, const void* cat, void* dz, void* dcat, int B, int D, hipStream_t st) {
+  DT(hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(g1((size_t)B * D)), dim3(256), 0, st, (const float*)dfused, (const float*)z, (const float*)cat, (float*)dz, (float*)dcat, B, D),
+     hipLaunchKernelGGL(gate_bwd_kernel<bf16_t>, dim3(g1((size_t)B * D)), dim3(256), 0, st, (const bf16_t*)dfused, (const bf16_t*)z, (const bf16_t*)cat, (bf16_t*)dz, (bf16_t*)dcat, B, D));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_add(int dtype, const void* a, const void* b, void* out, long long n, hipStream_t st) {
+  DT(hipLaunchKernelGGL(add_kernel<float>, dim3(g1((size_t)n)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, (size_t)n),
+     hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(g1((size_t)n)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (size_t)n));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+// outact != null: relu (and dropout folded into out>0); outact == null && p>0: dropout mask regenerated from (seed, index)
+int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, float* dbias, int M, int N, float p, unsigned long long seed, hipStream_t st) {
+  int gy = (M + 127) / 128; if (gy > 256) gy = 256; if (gy < 1) gy = 1;
+  dim3 grid((N + 63) / 64, gy);
+  DT(hipLaunchKernelGGL(bias_act_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)outact, (float*)dz, dbias, M, N, 0, p, seed),
+     hipLaunchKernelGGL(bias_act_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (bf16_t*)dz, dbias, M, N, 0, p, seed));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_cross_entropy(int dtype, const void* logits, const long long* targets, float* loss, void* dlogits, float* logits_f32, int B, int N,
+                      float gscale, hipStream_t st) {
+  dim3 grid((B + 3) / 4);
+  DT(hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, targets, loss, (float*)dlogits, logits_f32, B, N, gscale),
+     hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)logits, targets, loss, (bf16_t*)dlogits, logits_f32, B, N, gscale));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+// dtype_in / dtype_out: 0 = f32, 1 = bf16
+int vqa_convert(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t st) {
+  const unsigned g = g1((size_t)n);
+  if (!dtype_in && dtype_out) hipLaunchKernelGGL((convert_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)in, (bf16_t*)out, (size_t)n);
+  else if (dtype_in && !dtype_out) hipLaunchKernelGGL((convert_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)in, (float*)out, (size_t)n);
+  else if (!dtype_in) hipLaunchKernelGGL((convert_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)in, (float*)out, (size_t)n);
+  else hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, (size_t)n);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_sumsq(const float* g, long long n, float* out, hipStream_t st) {
+  size_t blocks = ((size_t)n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, (size_t)n, out);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
+              float bc1, float bc2, const float* sumsq, float max_norm, float gscale, hipStream_t st) {
+  size_t blocks = ((size_t)n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, bc1, bc2, sumsq, max_norm, gscale);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+
+}  // extern "C"

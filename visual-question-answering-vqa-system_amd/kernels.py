@@ -1,0 +1,126 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per exported kernel family).
+
+Layouts: CNN activations are NHWC `[B, H, W, C]`, tokens `[rows, D]`; compute dtype T is float32 (parity
+path, fp32 MFMA) or bfloat16 (throughput path, bf16 MFMA with fp32 accumulation).  All statistics,
+coefficients, weight gradients and optimizer state are float32.  Functions allocate outputs with torch
+(the caching allocator is the only allocator) and launch on the current stream.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from ._lib import call, dt, ptr
+
+LOADER_NHWC, LOADER_STEM = 0, 1
+
+
+def _bk(dtype):
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def pack_rows(w2d: torch.Tensor, dtype, kp=None) -> torch.Tensor:
+    """[N][K] fp32 -> [N][Kp] T (zero padded)."""
+    n, k = w2d.shape
+    kp = k if kp is None else kp
+    if dtype == torch.float32 and kp == k:
+        return w2d
+    out = torch.empty((n, kp), device=w2d.device, dtype=dtype)
+    call("vqa_pack_rows", dt(dtype), ptr(w2d), ptr(out), n, k, kp)
+    return out
+
+
+def pack_transpose(w3d: torch.Tensor, dtype) -> torch.Tensor:
+    """[N][T][C] fp32 -> [C][T][N] T (the data-gradient operand)."""
+    n, t, c = w3d.shape
+    out = torch.empty((c, t, n), device=w3d.device, dtype=dtype)
+    call("vqa_pack_transpose", dt(dtype), ptr(w3d), ptr(out), n, t, c)
+    return out
+
+
+def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=None, addmask=None, want_stats=False,
+          transposed=0, relu=0, drop_p=0.0, drop_seed=0, out=None):
+    """out[M][N] = gather(a) @ w[N][Kw]^T with the fused epilogue.  geom = (B, H, W, C, Ho, Wo, R, S, stride, pad).
+    Returns (out, stats_slab | None, mtiles)."""
+    B, H, W, C, Ho, Wo, R, S, stride, pad = geom
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=dtype)
+    stats, mt = None, 0
+    if want_stats:
+        mt = L.count("vqa_igemm_mtiles", M, N, loader)
+        stats = torch.empty((mt, 2, N), device=a.device, dtype=torch.float32)
+    call("vqa_igemm", dt(dtype), loader, ptr(a), ptr(w), ptr(out), ptr(bias), ptr(addend), ptr(addmask), ptr(stats),
+         M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad, transposed, relu, float(drop_p), int(drop_seed))
+    return out, stats, mt
+
+
+def wgrad(dy, x, dw, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC):
+    """dw[N][Kw] (fp32) += dy[M][N]^T @ gather(x)[M][Kw]."""
+    B, H, W, C, Ho, Wo, R, S, stride, pad = geom
+    call("vqa_wgrad", dt(dtype), loader, ptr(dy), ptr(x), ptr(dw), M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad)
+
+
+def linear_geom(M, K):
+    return (M, 1, 1, K, 1, 1, 1, 1, 1, 0)
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchNorm
+# ----------------------------------------------------------------------------------------------
+def bn_train_coef(stats, mtiles, C, count, gamma, beta, rm, rv, nbt, momentum=0.1, eps=1e-5):
+    scratch = torch.empty((64 * 2 * C,), device=stats.device, dtype=torch.float64)
+    coef = torch.empty((4, C), device=stats.device, dtype=torch.float32)
+    call("vqa_bn_stats_finalize", ptr(stats), mtiles, C, float(count), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt),
+         momentum, eps, ptr(scratch), ptr(coef))
+    return coef
+
+
+def bn_eval_coef(C, gamma, beta, rm, rv, eps=1e-5):
+    coef = torch.empty((4, C), device=gamma.device, dtype=torch.float32)
+    call("vqa_bn_eval_coef", C, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), eps, ptr(coef))
+    return coef
+
+
+def bn_apply(y, coef, C, relu, res=None, rcoef=None):
+    out = torch.empty_like(y)
+    call("vqa_bn_apply", dt(y), ptr(y), ptr(coef), ptr(res), ptr(rcoef), ptr(out), y.numel(), C, int(relu))
+    return out
+
+
+def bn_bwd(dout, outact, y, coef, gamma, C, training, dgamma, dbeta, y2=None, coef2=None, gamma2=None, dgamma2=None, dbeta2=None):
+    """BatchNorm backward for g = dout*(outact>0); optional second BN (1x1 shortcut) sharing g.
+    Returns dy (and dy2)."""
+    rows = y.numel() // C
+    nb = L.count("vqa_bn_bwd_blocks", rows)
+    slab = torch.empty((nb, 3, C), device=y.device, dtype=torch.float32)
+    call("vqa_bn_bwd_reduce", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(coef), ptr(y2), ptr(coef2), ptr(slab), rows, C)
+    bc = torch.empty((3, C), device=y.device, dtype=torch.float32)
+    call("vqa_bn_bwd_finalize", ptr(slab), nb, C, 1, float(rows), ptr(gamma), ptr(coef), int(training), ptr(dgamma), ptr(dbeta), ptr(bc))
+    dy = torch.empty_like(y)
+    dy2 = bc2 = None
+    if y2 is not None:
+        bc2 = torch.empty((3, C), device=y.device, dtype=torch.float32)
+        call("vqa_bn_bwd_finalize", ptr(slab), nb, C, 2, float(rows), ptr(gamma2), ptr(coef2), int(training), ptr(dgamma2), ptr(dbeta2), ptr(bc2))
+        dy2 = torch.empty_like(y2)
+    call("vqa_bn_bwd_apply", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(bc), ptr(dy), ptr(y2), ptr(bc2), ptr(dy2), y.numel(), C)
+    return dy, dy2
+
+
+# ----------------------------------------------------------------------------------------------
+# token side helpers
+# ----------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, *, eps=1e-5, drop_p=0.0, seed=0, addrow=None, period=1):
+    rows, D = x.shape
+    out = torch.empty_like(x)
+    stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    call("vqa_layernorm_fwd", dt(x), ptr(x), ptr(gamma), ptr(beta), ptr(out), ptr(stats), rows, D, eps, float(drop_p), int(seed),
+         ptr(addrow), period)
+    return out, stats
+
+
+def layernorm_bwd(dout, x, gamma, stats, dgamma, dbeta, *, addend=None, drop_p=0.0, seed=0, dadd=None, period=1):
+    rows, D = x.shape
+    dx = torch.empty_like(x)
+    call("vqa_layernorm_bwd", dt(x), ptr(dout), ptr(x), ptr(gamma), ptr(stats), ptr(addend), ptr(dx), ptr(dgamma), ptr(dbeta),
+         rows, D, float(drop_p), int(seed), ptr(dadd), period)
+    return dx
