@@ -4,3 +4,24 @@ Import with importlib (the directory name is not a Python identifier):
     pkg = importlib.import_module("visual-question-answering-vqa-system_amd")
 """
 from . import _lib, kernels  # noqa: F401
+from . import layout, engine  # noqa: F401,E402
+
+
+def dropin_path() -> str:
+    """Directory to put on sys.path so that `from models.vqa_model import VQAModel` resolves to the HIP drop-in."""
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
+
+
+def load_dropin():
+    """Import the drop-in `models.vqa_model` without disturbing an already imported `models` package."""
+    import importlib.util, os, sys
+    name = "vqa_hip_dropin_models_vqa_model"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(dropin_path(), "models", "vqa_model.py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod

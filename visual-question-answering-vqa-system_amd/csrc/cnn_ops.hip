@@ -73,7 +73,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict
     for (int j = 0; j < VEC; ++j) {
       float x = v.get(j) * coef[c0 + j] + coef[C + c0 + j];
       if (res) x += rcoef ? (r.get(j) * rcoef[c0 + j] + rcoef[C + c0 + j]) : r.get(j);
-      o.set(j, relu ? fmaxf(x, 0.f) : x);
+      o.set(j, (relu && x < 0.f) ? 0.f : x);   // NaN-propagating ReLU like torch
     }
     stg16(out + i * VEC, o);
   }
@@ -193,8 +193,9 @@ __global__ void stem_pool_fwd_kernel(const T* __restrict__ y, const float* __res
         Vec16<T> yy = ldg16(y + (((size_t)b * H + ih) * W + iw) * C + c0);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          const float a = fmaxf(yy.get(j) * coef[c0 + j] + coef[C + c0 + j], 0.f);
-          if (a > best[j]) { best[j] = a; bi[j] = r * 3 + s; }     // first max wins (ATen max_pool2d)
+          float a = yy.get(j) * coef[c0 + j] + coef[C + c0 + j];
+          a = a < 0.f ? 0.f : a;
+          if (a > best[j] || a != a) { best[j] = a; bi[j] = r * 3 + s; }     // first max wins, NaN propagates (ATen max_pool2d)
         }
       }
     }

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[i][j][r] + bv;
-          acc[i][j][r] = p.relu ? fmaxf(v, 0.f) : v;
+          acc[i][j][r] = (p.relu && v < 0.f) ? 0.f : v;   // NaN-propagating ReLU like torch
         }
     }
   }

@@ -1,0 +1,503 @@
+"""Explicit forward/backward executor of the VQA model over the HIP kernels (no autograd inside).
+
+`HipEngine.forward` replays VQAModel.forward (reference models/vqa_model.py:243-311) as a fixed sequence of
+C-ABI kernel launches on the current stream and records a tape; `HipEngine.backward` walks the tape in
+reverse, writing every parameter gradient into a flat fp32 gradient buffer (same layout as the parameters)
+and calling `on_segment(name)` after each group of layers has enqueued its last gradient kernel
+(answer_head, fusion, text_encoder, stage4 ... stem) so a data-parallel driver can start that bucket's
+RCCL all-reduce while earlier layers are still running.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import kernels as K
+from . import layout as LY
+from ._lib import call, dt, ptr
+
+
+class HipEngine:
+    def __init__(self, cfg: dict, entries: List[LY.Entry], flat: torch.Tensor, buffers: Dict[str, torch.Tensor],
+                 compute_dtype: torch.dtype):
+        self.cfg = cfg
+        self.entries = entries
+        self.E = {e.name: e for e in entries}
+        self.flat = flat
+        self.buf = buffers
+        self.dtype = compute_dtype
+        self.seed_base = 0x5EED
+        self.step_id = 0
+        self.wsrc = flat
+        self._wt: Dict[str, torch.Tensor] = {}
+        self.stem_w = None
+
+    # ------------------------------------------------------------------ parameter access
+    def P(self, name):                       # fp32 master, flat 1-D
+        e = self.E[name]
+        return self.flat[e.offset: e.offset + e.numel]
+
+    def Wm(self, name):                      # [N][K] operand in compute dtype
+        return LY.mat_of(self.wsrc, self.E[name])
+
+    def Wt(self, name):                      # [C][T][N] data-gradient operand, packed once per step
+        t = self._wt.get(name)
+        if t is None:
+            e = self.E[name]
+            n = e.shape[0]
+            c = e.shape[1]
+            tt = e.numel // (n * c)
+            t = K.pack_transpose(LY.mat_of(self.flat, e).view(n, tt, c), self.dtype)
+            self._wt[name] = t
+        return t
+
+    def begin_step(self):
+        """Refresh the working copies of the weights (one cast of the whole flat buffer in bf16 mode)."""
+        self._wt = {}
+        if self.dtype == torch.bfloat16:
+            if self.wsrc is self.flat or self.wsrc.numel() != self.flat.numel():
+                self.wsrc = torch.empty(self.flat.numel(), device=self.flat.device, dtype=torch.bfloat16)
+            call("vqa_convert", 0, 1, ptr(self.flat), ptr(self.wsrc), self.flat.numel())
+        else:
+            self.wsrc = self.flat
+        bk = 64 if self.dtype == torch.bfloat16 else 32
+        kp = (147 + bk - 1) // bk * bk
+        self.stem_kp = kp
+        self.stem_w = K.pack_rows(LY.mat_of(self.flat, self.E["image_encoder.stem.0.weight"]), self.dtype, kp)
+
+    def _seed(self):
+        self._site += 1
+        return (self.seed_base + self.step_id) * 4096 + self._site
+
+    # ------------------------------------------------------------------ small op helpers
+    def _bn_coef(self, prefix, stats, mt, C, count, training):
+        if training:
+            return K.bn_train_coef(stats, mt, C, count, self.P(prefix + ".weight"), self.P(prefix + ".bias"),
+                                   self.buf[prefix + ".running_mean"], self.buf[prefix + ".running_var"],
+                                   self.buf[prefix + ".num_batches_tracked"])
+        return K.bn_eval_coef(C, self.P(prefix + ".weight"), self.P(prefix + ".bias"),
+                              self.buf[prefix + ".running_mean"], self.buf[prefix + ".running_var"])
+
+    def _conv(self, x, B, H, W, Cin, wname, Cout, R, stride, pad, stats):
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+        M = B * Ho * Wo
+        geom = (B, H, W, Cin, Ho, Wo, R, R, stride, pad)
+        y, st, mt = K.igemm(x, self.Wm(wname), M, Cout, R * R * Cin, geom, dtype=self.dtype, want_stats=stats)
+        return y, st, mt, geom, Ho, Wo
+
+    def _lin(self, x, wname, bname=None, relu=0, p=0.0, seed=0, addend=None):
+        e = self.E[wname]
+        N, Kin = e.shape[0], e.shape[1]
+        M = x.shape[0]
+        if N % 8:                                  # rare (e.g. num_answers=10): run the GEMM on a zero-padded copy of W
+            Np = (N + 7) // 8 * 8
+            w = torch.zeros((Np, Kin), device=x.device, dtype=self.dtype)
+            w[:N] = self.Wm(wname)
+            b = None
+            if bname:
+                b = torch.zeros((Np,), device=x.device, dtype=torch.float32)
+                b[:N] = self.P(bname)
+            assert addend is None and p == 0.0
+            out, _, _ = K.igemm(x, w, M, Np, Kin, K.linear_geom(M, Kin), dtype=self.dtype, bias=b, relu=relu)
+            return out[:, :N].contiguous()
+        out, _, _ = K.igemm(x, self.Wm(wname), M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype,
+                            bias=self.P(bname) if bname else None, relu=relu, drop_p=p, drop_seed=seed, addend=addend)
+        return out
+
+    def _lin_bwd(self, dz, x_in, wname, G, need_dx=True, addend=None):
+        """dW += dz^T x ; returns dx = dz W (+ addend)."""
+        e = self.E[wname]
+        N, Kin = e.shape[0], e.shape[1]
+        M = dz.shape[0]
+        if N % 8:
+            Np = (N + 7) // 8 * 8
+            dzp = torch.zeros((M, Np), device=dz.device, dtype=self.dtype)
+            dzp[:, :N] = dz
+            dwp = torch.zeros((Np, Kin), device=dz.device, dtype=torch.float32)
+            K.wgrad(dzp, x_in, dwp, M, Np, Kin, K.linear_geom(M, Kin), dtype=self.dtype)
+            LY.mat_of(G, e).add_(dwp[:N])
+            if not need_dx:
+                return None
+            wp = torch.zeros((Np, 1, Kin), device=dz.device, dtype=torch.float32)
+            wp[:N, 0] = LY.mat_of(self.flat, e)
+            dx, _, _ = K.igemm(dzp, K.pack_transpose(wp, self.dtype), M, Kin, Np, K.linear_geom(M, Np), dtype=self.dtype, addend=addend)
+            return dx
+        K.wgrad(dz, x_in, LY.mat_of(G, e), M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype)
+        if not need_dx:
+            return None
+        dx, _, _ = K.igemm(dz, self.Wt(wname), M, Kin, N, K.linear_geom(M, N), dtype=self.dtype, addend=addend)
+        return dx
+
+    def _act_bwd(self, dout, outact, bname, G, p, seed):
+        """Gradient at the pre-activation of `linear(+bias)(+relu)(+dropout)`; accumulates the bias gradient."""
+        M, N = dout.shape
+        need_dz = (outact is not None) or p > 0.0
+        dz = torch.empty_like(dout) if need_dz else None
+        dbias = None
+        if bname:
+            e = self.E[bname]
+            dbias = G[e.offset: e.offset + e.numel]
+        if need_dz or dbias is not None:
+            call("vqa_bias_act_bwd", dt(dout), ptr(dout), ptr(outact), ptr(dz), ptr(dbias), M, N, float(p), int(seed))
+        return dz if need_dz else dout
+
+    def _ln(self, x, prefix, p=0.0, seed=0, addrow=None, period=1):
+        return K.layernorm_fwd(x, self.P(prefix + ".weight"), self.P(prefix + ".bias"), drop_p=p, seed=seed,
+                               addrow=addrow, period=period)
+
+    def _ln_bwd(self, dout, x, prefix, stats, G, addend=None, p=0.0, seed=0, dadd=None, period=1):
+        eg, eb = self.E[prefix + ".weight"], self.E[prefix + ".bias"]
+        return K.layernorm_bwd(dout, x, self.P(prefix + ".weight"), stats, G[eg.offset: eg.offset + eg.numel],
+                               G[eb.offset: eb.offset + eb.numel], addend=addend, drop_p=p, seed=seed, dadd=dadd, period=period)
+
+    def _gslice(self, G, name):
+        e = self.E[name]
+        return G[e.offset: e.offset + e.numel]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images: torch.Tensor, token_ids: torch.Tensor, maskf: Optional[torch.Tensor], training: bool,
+                want_aux: bool = False, need_tape: bool = True):
+        cfg, T = self.cfg, self.dtype
+        self._site = 0
+        self.begin_step()
+        tape: dict = {"training": training, "B": images.shape[0]}
+        B, _, IH, IW = images.shape
+        pdrop = cfg["dropout"] if training else 0.0
+        phead = cfg["answer_dropout"] if training else 0.0
+        dev = images.device
+
+        # ---- stem: conv7x7/2 (from the NCHW fp32 image) + BN + ReLU + maxpool, A1
+        H1, W1 = (IH + 6 - 7) // 2 + 1, (IW + 6 - 7) // 2 + 1
+        M = B * H1 * W1
+        sgeom = (B, IH, IW, 3, H1, W1, 7, 7, 2, 3)
+        y, st, mt = K.igemm(images, self.stem_w, M, 64, self.stem_kp, sgeom, dtype=T, loader=K.LOADER_STEM, want_stats=training)
+        coef = self._bn_coef("image_encoder.stem.1", st, mt, 64, M, training)
+        Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+        x = torch.empty((B * Hp * Wp, 64), device=dev, dtype=T)
+        idx = torch.empty((B * Hp * Wp, 64), device=dev, dtype=torch.uint8)
+        call("vqa_stem_pool_fwd", dt(T), ptr(y), ptr(coef), ptr(x), ptr(idx), B, H1, W1, 64)
+        tape["stem"] = dict(images=images, y=y, coef=coef, idx=idx, geom=sgeom, H1=H1, W1=W1)
+        H, W, C = Hp, Wp, 64
+
+        # ---- residual stages, A2-A5
+        tape["stages"] = []
+        for s, Cout in enumerate(LY.STAGE_CHANNELS, start=1):
+            srec = {"blocks": []}
+            for b in range(2):
+                p = f"image_encoder.stage{s}.blocks.{b}"
+                stride = 2 if (b == 0 and s > 1) else 1
+                Cin = C
+                y1, st1, mt1, g1, Ho, Wo = self._conv(x, B, H, W, Cin, p + ".conv1.weight", Cout, 3, stride, 1, training)
+                M = B * Ho * Wo
+                c1 = self._bn_coef(p + ".bn1", st1, mt1, Cout, M, training)
+                a1 = K.bn_apply(y1, c1, Cout, relu=True)
+                y2, st2, mt2, g2, _, _ = self._conv(a1, B, Ho, Wo, Cout, p + ".conv2.weight", Cout, 3, 1, 1, training)
+                c2 = self._bn_coef(p + ".bn2", st2, mt2, Cout, M, training)
+                rec = dict(p=p, x=x, y1=y1, c1=c1, a1=a1, y2=y2, c2=c2, g1=g1, g2=g2, M=M, Cin=Cin, Cout=Cout)
+                if (p + ".downsample.0.weight") in self.E:
+                    yd, std, mtd, gd, _, _ = self._conv(x, B, H, W, Cin, p + ".downsample.0.weight", Cout, 1, stride, 0, training)
+                    cd = self._bn_coef(p + ".downsample.1", std, mtd, Cout, M, training)
+                    out = K.bn_apply(y2, c2, Cout, relu=True, res=yd, rcoef=cd)
+                    rec.update(yd=yd, cd=cd, gd=gd)
+                else:
+                    out = K.bn_apply(y2, c2, Cout, relu=True, res=x)
+                rec["out"] = out
+                srec["blocks"].append(rec)
+                x, H, W, C = out, Ho, Wo, Cout
+            ap = f"image_encoder.stage{s}.attention"
+            if (ap + ".se.fc1.weight") in self.E:
+                Cr = self.E[ap + ".se.fc1.weight"].shape[0]
+                pooled = torch.empty((B, C), device=dev, dtype=torch.float32)
+                hidden = torch.empty((B, Cr), device=dev, dtype=torch.float32)
+                scale = torch.empty((B, C), device=dev, dtype=torch.float32)
+                out = torch.empty_like(x)
+                call("vqa_se_fwd", dt(T), ptr(x), ptr(self.P(ap + ".se.fc1.weight")), ptr(self.P(ap + ".se.fc2.weight")),
+                     ptr(pooled), ptr(hidden), ptr(scale), ptr(out), B, H * W, C, Cr)
+                srec["se"] = dict(x=x, pooled=pooled, hidden=hidden, scale=scale, Cr=Cr, HW=H * W, C=C)
+                x = out
+            if (ap + ".spatial.conv.weight") in self.E:
+                pooled2 = torch.empty((B * H * W, 2), device=dev, dtype=torch.float32)
+                amax = torch.empty((B * H * W,), device=dev, dtype=torch.int32)
+                amap = torch.empty((B * H * W,), device=dev, dtype=torch.float32)
+                out = torch.empty_like(x)
+                call("vqa_spatial_fwd", dt(T), ptr(x), ptr(self.P(ap + ".spatial.conv.weight")), ptr(pooled2), ptr(amax),
+                     ptr(amap), ptr(out), B, H, W, C)
+                srec["spatial"] = dict(x=x, pooled2=pooled2, amax=amax, amap=amap, H=H, W=W, C=C)
+                x = out
+            tape["stages"].append(srec)
+        feat = x                                  # [B*Hf*Wf, 512] == tokens of the projector (NHWC makes the permute free)
+        Hf, Wf, Cf = H, W, C
+        ntok = Hf * Wf
+        tape["feat"] = dict(Hf=Hf, Wf=Wf, Cf=Cf)
+
+        # ---- text encoder, A6-A8
+        d, heads = cfg["embed_dim"], cfg["num_attention_heads"]
+        hd = d // heads
+        Bt, L = token_ids.shape
+        rows = Bt * L
+        pe = self.buf["text_encoder.positional_encoding.pe"]
+        if L > pe.shape[1]:
+            raise RuntimeError(f"sequence length {L} exceeds max_question_length {pe.shape[1]}")
+        emb_e = self.E["text_encoder.token_embedding.weight"]
+        sd0 = self._seed()
+        xt = torch.empty((rows, d), device=dev, dtype=T)
+        call("vqa_embed_fwd", dt(T), ptr(token_ids), ptr(self.P(emb_e.name)), ptr(pe), ptr(xt), rows, L, d, emb_e.shape[0],
+             math.sqrt(d), float(pdrop), sd0)
+        tape["embed"] = dict(ids=token_ids, seed=sd0, p=pdrop)
+        tape["tlayers"] = []
+        for l in range(cfg["num_transformer_layers"]):
+            p = f"text_encoder.layers.{l}"
+            rec = self._attn_block_fwd(xt, xt, None, p + ".norm1", None, p + ".self_attention", maskf, Bt, L, L, heads, hd, pdrop,
+                                       p + ".norm2", p + ".ffn.fc1", p + ".ffn.fc2", self_attn=True)
+            tape["tlayers"].append(rec)
+            xt = rec["out"]
+        enc, enc_st = self._ln(xt, "text_encoder.final_norm")
+        tape["final_norm"] = dict(x=xt, st=enc_st)
+
+        # ---- fusion, A9-A11
+        pj = "fusion.image_projector.projection"
+        pz = self._lin(feat, pj + ".0.weight", pj + ".0.bias")
+        sdp = self._seed()
+        posemb = self.P("fusion.image_projector.position_embedding")
+        img, img_st = self._ln(pz, pj + ".1", p=pdrop, seed=sdp, addrow=posemb, period=ntok)
+        tape["proj"] = dict(feat=feat, pz=pz, st=img_st, seed=sdp, p=pdrop, ntok=ntok)
+        q = enc
+        tape["clayers"] = []
+        probs_all = []
+        for l in range(cfg["num_cross_layers"]):
+            p = f"fusion.cross_attention.layers.{l}"
+            rec = self._attn_block_fwd(q, img, None, p + ".norm_query", p + ".norm_kv", p + ".cross_attention", None, Bt, L, ntok,
+                                       heads, hd, pdrop, p + ".norm_ffn", p + ".ffn.0", p + ".ffn.3", self_attn=False)
+            tape["clayers"].append(rec)
+            probs_all.append(rec["probs"])
+            q = rec["out"]
+        cat = torch.empty((Bt, 2 * d), device=dev, dtype=T)
+        call("vqa_masked_pool_fwd", dt(T), ptr(q), ptr(maskf), ptr(cat), 2 * d, 0, Bt, L, d)
+        call("vqa_masked_pool_fwd", dt(T), ptr(enc), ptr(maskf), ptr(cat), 2 * d, d, Bt, L, d)
+        fused_pre = torch.empty((Bt, d), device=dev, dtype=T)
+        z = None
+        if cfg["use_gating"]:
+            z = self._lin(cat, "fusion.gate.gate.0.weight", "fusion.gate.gate.0.bias")
+            call("vqa_gate_fwd", dt(T), ptr(z), ptr(cat), ptr(fused_pre), Bt, d)
+        else:
+            att = cat[:, :d].contiguous(); txt = cat[:, d:].contiguous()
+            call("vqa_add", dt(T), ptr(att), ptr(txt), ptr(fused_pre), Bt * d)
+        fused, fst = self._ln(fused_pre, "fusion.output_norm")
+        tape["pool"] = dict(q=q, enc=enc, cat=cat, z=z, fused_pre=fused_pre, fst=fst, maskf=maskf, L=L, d=d)
+
+        # ---- answer head, A12
+        c = "answer_head.classifier"
+        s1, s2 = self._seed(), self._seed()
+        h1 = self._lin(fused, c + ".0.weight", c + ".0.bias", relu=1, p=phead, seed=s1)
+        h2 = self._lin(h1, c + ".3.weight", c + ".3.bias", relu=1, p=phead, seed=s2)
+        logits = self._lin(h2, c + ".6.weight", c + ".6.bias")
+        tape["head"] = dict(fused=fused, h1=h1, h2=h2, s1=s1, s2=s2, p=phead)
+        logits_f = logits.float() if T != torch.float32 else logits
+
+        aux = None
+        if want_aux:
+            feat_nchw = torch.empty((B, Cf, Hf, Wf), device=dev, dtype=torch.float32)
+            call("vqa_nhwc_to_nchw", dt(T), ptr(feat), ptr(feat_nchw), B, Hf * Wf, Cf)
+            aux = {
+                "image_features": feat_nchw,
+                "text_features": enc.float().view(Bt, L, d),
+                "text_pooled": cat[:, d:].float(),          # fusion's entry overrides the encoder's (vqa_model.py:303-309)
+                "fused": fused.float(),
+                "cross_attention_weights": probs_all,
+                "image_projected": img.float().view(Bt, ntok, d),
+                "attended_pooled": cat[:, :d].float(),
+            }
+        if not need_tape:
+            tape = None
+        return logits_f, aux, tape
+
+    def _attn_block_fwd(self, q_in, kv_in, _unused, norm_q, norm_kv, attn, kmask, B, Lq, Lk, heads, hd, p, norm_f, fc1, fc2, self_attn):
+        """pre-norm attention + FFN block (TransformerEncoderLayer.forward text_encoder.py:373-399 and
+        MultiHeadCrossAttention.forward cross_attention.py:285-299)."""
+        T = self.dtype
+        d = heads * hd
+        nq, stq = self._ln(q_in, norm_q)
+        if self_attn:
+            nkv, stkv = nq, None
+        else:
+            nkv, stkv = self._ln(kv_in, norm_kv)
+        Q = self._lin(nq, attn + ".W_q.weight")
+        Kt = self._lin(nkv, attn + ".W_k.weight")
+        V = self._lin(nkv, attn + ".W_v.weight")
+        probs = torch.empty((B, heads, Lq, Lk), device=Q.device, dtype=torch.float32)
+        ctx = torch.empty((B * Lq, d), device=Q.device, dtype=T)
+        sa = self._seed()
+        call("vqa_attention_fwd", dt(T), ptr(Q), ptr(Kt), ptr(V), d, d, d, ptr(kmask), ptr(probs), ptr(ctx), d, B, heads, Lq, Lk, hd,
+             float(p), sa)
+        so = self._seed()
+        x1 = self._lin(ctx, attn + ".W_o.weight", p=p, seed=so, addend=q_in)
+        nf, stf = self._ln(x1, norm_f)
+        s1, s2 = self._seed(), self._seed()
+        h = self._lin(nf, fc1 + ".weight", fc1 + ".bias", relu=1, p=p, seed=s1)
+        out = self._lin(h, fc2 + ".weight", fc2 + ".bias", p=p, seed=s2, addend=x1)
+        return dict(q_in=q_in, kv_in=kv_in, nq=nq, stq=stq, nkv=nkv, stkv=stkv, Q=Q, K=Kt, V=V, probs=probs, ctx=ctx, sa=sa, so=so,
+                    x1=x1, nf=nf, stf=stf, h=h, s1=s1, s2=s2, out=out, p=p, norm_q=norm_q, norm_kv=norm_kv, attn=attn, norm_f=norm_f,
+                    fc1=fc1, fc2=fc2, self_attn=self_attn, B=B, Lq=Lq, Lk=Lk, heads=heads, hd=hd)
+
+    def _attn_block_bwd(self, rec, dout, G, dkv_addend=None):
+        """Returns (d q_in, d kv_in) ; for self-attention d kv_in is folded into d q_in."""
+        T = self.dtype
+        p, B, Lq, Lk, heads, hd = rec["p"], rec["B"], rec["Lq"], rec["Lk"], rec["heads"], rec["hd"]
+        d = heads * hd
+        attn, fc1, fc2 = rec["attn"], rec["fc1"], rec["fc2"]
+        dz2 = self._act_bwd(dout, None, fc2 + ".bias", G, p, rec["s2"])
+        dh = self._lin_bwd(dz2, rec["h"], fc2 + ".weight", G)
+        dz1 = self._act_bwd(dh, rec["h"], fc1 + ".bias", G, p, rec["s1"])
+        dnf = self._lin_bwd(dz1, rec["nf"], fc1 + ".weight", G)
+        dx1 = self._ln_bwd(dnf, rec["x1"], rec["norm_f"], rec["stf"], G, addend=dout)
+        dzo = self._act_bwd(dx1, None, None, G, p, rec["so"])
+        dctx = self._lin_bwd(dzo, rec["ctx"], attn + ".W_o.weight", G)
+        dQ = torch.empty_like(rec["Q"]); dK = torch.empty_like(rec["K"]); dV = torch.empty_like(rec["V"])
+        call("vqa_attention_bwd", dt(T), ptr(dctx), d, ptr(rec["Q"]), ptr(rec["K"]), ptr(rec["V"]), d, d, d, ptr(rec["probs"]),
+             ptr(dQ), ptr(dK), ptr(dV), d, d, d, B, heads, Lq, Lk, hd, float(p), rec["sa"])
+        dnq = self._lin_bwd(dQ, rec["nq"], attn + ".W_q.weight", G)
+        if rec["self_attn"]:
+            dnq = self._lin_bwd(dK, rec["nkv"], attn + ".W_k.weight", G, addend=dnq)
+            dnq = self._lin_bwd(dV, rec["nkv"], attn + ".W_v.weight", G, addend=dnq)
+            dq_in = self._ln_bwd(dnq, rec["q_in"], rec["norm_q"], rec["stq"], G, addend=dx1)
+            return dq_in, None
+        dnkv = self._lin_bwd(dK, rec["nkv"], attn + ".W_k.weight", G)
+        dnkv = self._lin_bwd(dV, rec["nkv"], attn + ".W_v.weight", G, addend=dnkv)
+        dq_in = self._ln_bwd(dnq, rec["q_in"], rec["norm_q"], rec["stq"], G, addend=dx1)
+        dkv_in = self._ln_bwd(dnkv, rec["kv_in"], rec["norm_kv"], rec["stkv"], G, addend=dkv_addend)
+        return dq_in, dkv_in
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, tape: dict, dlogits: torch.Tensor, G: torch.Tensor, on_segment: Optional[Callable[[str], None]] = None):
+        """G: flat fp32 gradient buffer (same layout as the parameters), accumulated into (+=)."""
+        cfg, T = self.cfg, self.dtype
+        training = tape["training"]
+        B = tape["B"]
+        seg = on_segment or (lambda name: None)
+        dl = dlogits.to(T).contiguous() if dlogits.dtype != T else dlogits.contiguous()
+
+        # ---- head
+        hdr = tape["head"]; c = "answer_head.classifier"
+        dz = self._act_bwd(dl, None, c + ".6.bias", G, 0.0, 0)
+        dh2 = self._lin_bwd(dz, hdr["h2"], c + ".6.weight", G)
+        dz = self._act_bwd(dh2, hdr["h2"], c + ".3.bias", G, hdr["p"], hdr["s2"])
+        dh1 = self._lin_bwd(dz, hdr["h1"], c + ".3.weight", G)
+        dz = self._act_bwd(dh1, hdr["h1"], c + ".0.bias", G, hdr["p"], hdr["s1"])
+        dfused = self._lin_bwd(dz, hdr["fused"], c + ".0.weight", G)
+        seg("answer_head")
+
+        # ---- fusion tail: output norm, gate, pools
+        pr = tape["pool"]; d, L = pr["d"], pr["L"]
+        dfp = self._ln_bwd(dfused, pr["fused_pre"], "fusion.output_norm", pr["fst"], G)
+        dcat = torch.empty_like(pr["cat"])
+        if cfg["use_gating"]:
+            dzg = torch.empty_like(pr["z"])
+            call("vqa_gate_bwd", dt(T), ptr(dfp), ptr(pr["z"]), ptr(pr["cat"]), ptr(dzg), ptr(dcat), B, d)
+            dzg = self._act_bwd(dzg, None, "fusion.gate.gate.0.bias", G, 0.0, 0)
+            dcat = self._lin_bwd(dzg, pr["cat"], "fusion.gate.gate.0.weight", G, addend=dcat)
+        else:
+            dcat[:, :d] = dfp; dcat[:, d:] = dfp
+        dq = torch.empty_like(pr["q"])
+        call("vqa_masked_pool_bwd", dt(T), ptr(dcat), 2 * d, 0, ptr(pr["maskf"]), None, ptr(dq), B, L, d)
+        denc = torch.empty_like(pr["enc"])
+        call("vqa_masked_pool_bwd", dt(T), ptr(dcat), 2 * d, d, ptr(pr["maskf"]), None, ptr(denc), B, L, d)
+        # ---- cross-attention layers (reverse); image-token gradient accumulates across layers
+        dimg = None
+        for rec in reversed(tape["clayers"]):
+            dq, dimg = self._attn_block_bwd(rec, dq, G, dkv_addend=dimg)
+        # dq is now the gradient wrt text features through the query path
+        call("vqa_add", dt(T), ptr(denc), ptr(dq), ptr(denc), denc.numel())
+        # ---- projector
+        pj = "fusion.image_projector.projection"; rp = tape["proj"]
+        dpos = self._gslice(G, "fusion.image_projector.position_embedding")
+        dpz = self._ln_bwd(dimg, rp["pz"], pj + ".1", rp["st"], G, p=rp["p"], seed=rp["seed"], dadd=dpos, period=rp["ntok"])
+        dpz = self._act_bwd(dpz, None, pj + ".0.bias", G, 0.0, 0)
+        dfeat = self._lin_bwd(dpz, rp["feat"], pj + ".0.weight", G)
+        seg("fusion")
+
+        # ---- text encoder
+        fn = tape["final_norm"]
+        dx = self._ln_bwd(denc, fn["x"], "text_encoder.final_norm", fn["st"], G)
+        for rec in reversed(tape["tlayers"]):
+            dx, _ = self._attn_block_bwd(rec, dx, G)
+        em = tape["embed"]; emb_e = self.E["text_encoder.token_embedding.weight"]
+        call("vqa_embed_bwd", dt(T), ptr(em["ids"]), ptr(dx), ptr(self._gslice(G, emb_e.name)), dx.shape[0], d, emb_e.shape[0],
+             math.sqrt(d), float(em["p"]), em["seed"])
+        seg("text_encoder")
+
+        # ---- CNN stages (reverse)
+        dxc = dfeat
+        for s in (4, 3, 2, 1):
+            srec = tape["stages"][s - 1]
+            ap = f"image_encoder.stage{s}.attention"
+            if "spatial" in srec:
+                r = srec["spatial"]
+                npix = B * r["H"] * r["W"]
+                scratch = torch.empty((npix * 3,), device=dxc.device, dtype=torch.float32)
+                dxn = torch.empty_like(r["x"])
+                call("vqa_spatial_bwd", dt(T), ptr(dxc), ptr(r["x"]), ptr(self.P(ap + ".spatial.conv.weight")), ptr(r["pooled2"]),
+                     ptr(r["amax"]), ptr(r["amap"]), ptr(scratch), ptr(dxn), ptr(self._gslice(G, ap + ".spatial.conv.weight")),
+                     B, r["H"], r["W"], r["C"])
+                dxc = dxn
+            if "se" in srec:
+                r = srec["se"]
+                scratch = torch.empty((B * (2 * r["C"] + r["Cr"]),), device=dxc.device, dtype=torch.float32)
+                dxn = torch.empty_like(r["x"])
+                call("vqa_se_bwd", dt(T), ptr(dxc), ptr(r["x"]), ptr(self.P(ap + ".se.fc1.weight")), ptr(self.P(ap + ".se.fc2.weight")),
+                     ptr(r["pooled"]), ptr(r["hidden"]), ptr(r["scale"]), ptr(scratch), ptr(dxn),
+                     ptr(self._gslice(G, ap + ".se.fc1.weight")), ptr(self._gslice(G, ap + ".se.fc2.weight")), B, r["HW"], r["C"], r["Cr"])
+                dxc = dxn
+            for rec in reversed(srec["blocks"]):
+                dxc = self._block_bwd(rec, dxc, G, training)
+            seg(f"image_encoder.stage{s}")
+
+        # ---- stem
+        st = tape["stem"]
+        Bq, IH, IW, _, H1, W1 = st["geom"][:6]
+        nb = K.L.count("vqa_bn_bwd_blocks", B * H1 * W1)
+        slab = torch.empty((nb, 3, 64), device=dxc.device, dtype=torch.float32)
+        call("vqa_stem_bwd_reduce", dt(T), ptr(dxc), ptr(st["idx"]), ptr(st["y"]), ptr(st["coef"]), ptr(slab), B, H1, W1, 64)
+        bc = torch.empty((3, 64), device=dxc.device, dtype=torch.float32)
+        bnp = "image_encoder.stem.1"
+        call("vqa_bn_bwd_finalize", ptr(slab), nb, 64, 1, float(B * H1 * W1), ptr(self.P(bnp + ".weight")), ptr(st["coef"]),
+             int(training), ptr(self._gslice(G, bnp + ".weight")), ptr(self._gslice(G, bnp + ".bias")), ptr(bc))
+        dy = torch.empty_like(st["y"])
+        call("vqa_stem_bwd_apply", dt(T), ptr(dxc), ptr(st["idx"]), ptr(st["y"]), ptr(st["coef"]), ptr(bc), ptr(dy), B, H1, W1, 64)
+        K.wgrad(dy, st["images"], LY.mat_of(G, self.E["image_encoder.stem.0.weight"]), B * H1 * W1, 64, 147, st["geom"], dtype=T,
+                loader=K.LOADER_STEM)
+        seg("image_encoder.stem")
+
+    def _block_bwd(self, rec, dout, G, training):
+        """ResidualBlock backward (reference forward: models/cnn_backbone.py:164-197)."""
+        T = self.dtype
+        p, Cout, Cin, M = rec["p"], rec["Cout"], rec["Cin"], rec["M"]
+        has_ds = "yd" in rec
+        gs = lambda n: self._gslice(G, n)
+        dy2, dyd = K.bn_bwd(dout, rec["out"], rec["y2"], rec["c2"], self.P(p + ".bn2.weight"), Cout, training,
+                            gs(p + ".bn2.weight"), gs(p + ".bn2.bias"),
+                            y2=rec.get("yd"), coef2=rec.get("cd"),
+                            gamma2=self.P(p + ".downsample.1.weight") if has_ds else None,
+                            dgamma2=gs(p + ".downsample.1.weight") if has_ds else None,
+                            dbeta2=gs(p + ".downsample.1.bias") if has_ds else None)
+        g2 = rec["g2"]; B, Ho, Wo = g2[0], g2[1], g2[2]
+        K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T)
+        geom_d2 = (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
+        da1, _, _ = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1)
+        dy1, _ = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["c1"], self.P(p + ".bn1.weight"), Cout, training,
+                          gs(p + ".bn1.weight"), gs(p + ".bn1.bias"))
+        g1 = rec["g1"]; H, W, stride = g1[1], g1[2], g1[8]
+        K.wgrad(dy1, rec["x"], LY.mat_of(G, self.E[p + ".conv1.weight"]), M, Cout, 9 * Cin, g1, dtype=T)
+        Md = B * H * W
+        geom_d1 = (B, Ho, Wo, Cout, H, W, 3, 3, stride, 1)
+        if has_ds:
+            gd = rec["gd"]
+            K.wgrad(dyd, rec["x"], LY.mat_of(G, self.E[p + ".downsample.0.weight"]), M, Cout, Cin, gd, dtype=T)
+            geom_dd = (B, Ho, Wo, Cout, H, W, 1, 1, stride, 0)
+            dxd, _, _ = K.igemm(dyd, self.Wt(p + ".downsample.0.weight"), Md, Cin, Cout, geom_dd, dtype=T, transposed=1)
+            dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1, addend=dxd)
+        else:
+            dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
+                               addend=dout, addmask=rec["out"])
+        return dx
