@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-question pairs/sec of a full train step (forward + CrossEntropy + backward + gradient
+all-reduce + clip_grad_norm_(1.0) + AdamW) of the VQA model, B=512 per GPU, 224x224 images, 20 tokens, bf16 MFMA.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     : dominant kernel (by time) of a train step, algorithmic FLOP/s from live event timings vs gfx950 MFMA peak
+  cpu_baseline : the CPU oracle (this repo's PyTorch restatement of the reference, parity-pinned by tests/golden) timed on
+                 the host cores on a bounded sample of the same workload (N=1 only).
+Inputs are synthetic (DemoVQADataset shapes, data/dataset.py:420-436) and resident in HBM before the timed region.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+PKG = "visual-question-answering-vqa-system_amd"
+FLOP_PER_PAIR = 11.311e9          # forward 3.849 + backward 7.462 GFLOP per pair
+PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+
+
+def synth_batch(B, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    images = torch.randn(B, 3, 224, 224, device=device, generator=g)
+    ids = torch.randint(0, 1000, (B, 20), device=device, generator=g)
+    lens = torch.randint(5, 21, (B,), device=device, generator=g)
+    mask = (torch.arange(20, device=device)[None, :] < lens[:, None]).long()
+    answers = torch.randint(0, 1000, (B,), device=device, generator=g)
+    return images, ids, mask, answers
+
+
+def cpu_baseline(seconds_budget=25.0):
+    from oracle import vqa_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))      # a 1-GPU box is given a 16-CPU share; more threads than that only thrash
+    torch.set_num_threads(cores)
+    cfg = O.full_config()
+    sd = O.init_state_dict(cfg, 0)
+    B = 8
+    images, ids, mask, answers = O.synthetic_batch(B, seed=1)
+    tr = O.OracleTrainer(sd, cfg)
+    tr.step(images, ids, mask, answers)          # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(images, ids, mask, answers)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 12:
+            break
+    return {"value": round(n * B / el, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fp32 train steps of the CPU oracle at batch {B} (same model/config, dropout on), {el:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    pkg = importlib.import_module(PKG)
+    M = pkg.load_dropin()
+    model = M.VQAModel(compute_dtype=args.dtype, seed=1234).to(dev).train()
+    trainer = pkg.trainer.HipTrainer(model, overlap=not args.no_overlap)
+    trainer.engine.seed_base += 7919 * rank
+    images, ids, mask, answers = synth_batch(args.batch, dev, 1234 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"model ready, batch {args.batch}/GPU x {world} GPU(s), dtype {args.dtype}")
+    for _ in range(args.warmup):
+        trainer.step(images, ids, mask, answers)
+    barrier()
+    note("warm-up done")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(images, ids, mask, answers)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    loss = float(trainer.loss.item())
+    ms = el / args.steps * 1e3
+    note(f"timed region done: {ms:.2f} ms/step")
+    value = args.batch * world * args.steps / el
+
+    # ---- live per-kernel timing of one more step (events on the launch stream) -> roofline of the dominant kernel
+    roof = None
+    if rank == 0:
+        K = pkg.kernels
+        K.PROFILE = []
+        trainer.step(images, ids, mask, answers)
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, e0, e1 in K.PROFILE:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += flops; a[2] += 1
+        K.PROFILE = None
+        gemm_time = sum(a[0] for a in agg.values())
+        name, (tt, fl, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        ach = fl / tt / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+                "frac": round(ach / PEAK[args.dtype], 4), "traffic": None, "launches_per_step": n,
+                "avg_launch_us": round(tt / n * 1e6, 2), "flop_per_launch": fl / n,
+                "kernel_share_of_step": round(tt / (ms * 1e-3), 3), "all_gemm_share_of_step": round(gemm_time / (ms * 1e-3), 3),
+                "step_tflops": round(value / world * FLOP_PER_PAIR / 1e12, 2),
+                "per_kernel": {k: {"ms": round(v[0] * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1), "n": v[2]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+    if world > 1:
+        dist.barrier()
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("timing the CPU oracle baseline (bounded sample)")
+        cpu = cpu_baseline()
+    if rank == 0:
+        out = {"metric": "image-question pairs/sec (train step)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"VQA train step fwd+CE+bwd+allreduce+clip+AdamW, batch {args.batch}/GPU, 3x224x224 images, 20 tokens, "
+                                      f"d=256, 1000 answers, dropout on (BASELINE configs[{2 if args.dtype == 'bf16' else 1}])",
+                          "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+               "final_loss": round(loss, 4), "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,7 +4,7 @@ Import with importlib (the directory name is not a Python identifier):
     pkg = importlib.import_module("visual-question-answering-vqa-system_amd")
 """
 from . import _lib, kernels  # noqa: F401
-from . import layout, engine  # noqa: F401,E402
+from . import layout, engine, trainer  # noqa: F401,E402
 
 
 def dropin_path() -> str:
@@ -15,7 +15,9 @@ def dropin_path() -> str:
 
 def load_dropin():
     """Import the drop-in `models.vqa_model` without disturbing an already imported `models` package."""
-    import importlib.util, os, sys
+    import importlib.util
+    import os
+    import sys
     name = "vqa_hip_dropin_models_vqa_model"
     if name in sys.modules:
         return sys.modules[name]

@@ -14,6 +14,23 @@ from ._lib import call, dt, ptr
 
 LOADER_NHWC, LOADER_STEM = 0, 1
 
+# Optional live profiling (bench.py): when PROFILE is a list, igemm/wgrad bracket their launch with events on the
+# launch stream and append (kernel symbol, algorithmic FLOPs, start event, end event).
+PROFILE = None
+
+
+def _tile(M, N, loader):
+    if loader == LOADER_STEM:
+        return 128, 64
+    bm, bn = (128, 64) if N <= 64 else (128, 128)
+    if ((M + bm - 1) // bm) * ((N + bn - 1) // bn) < 384:
+        bm, bn = 64, 64
+    return bm, bn
+
+
+def _tname(dtype):
+    return "unsigned short" if dtype == torch.bfloat16 else "float"
+
 
 def _bk(dtype):
     return 64 if dtype == torch.bfloat16 else 32
@@ -49,15 +66,32 @@ def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=
     if want_stats:
         mt = L.count("vqa_igemm_mtiles", M, N, loader)
         stats = torch.empty((mt, 2, N), device=a.device, dtype=torch.float32)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("vqa_igemm", dt(dtype), loader, ptr(a), ptr(w), ptr(out), ptr(bias), ptr(addend), ptr(addmask), ptr(stats),
          M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad, transposed, relu, float(drop_p), int(drop_seed))
+    if PROFILE is not None:
+        e1.record()
+        bm, bn = _tile(M, N, loader)
+        kreal = 147 if loader == LOADER_STEM else Kw
+        flops = 2.0 * B * H * W * C * R * S * N if transposed else 2.0 * M * N * kreal
+        PROFILE.append((f"igemm_kernel<{_tname(dtype)}, {bm}, {bn}, {loader}>", flops, e0, e1))
     return out, stats, mt
 
 
 def wgrad(dy, x, dw, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC):
     """dw[N][Kw] (fp32) += dy[M][N]^T @ gather(x)[M][Kw]."""
     B, H, W, C, Ho, Wo, R, S, stride, pad = geom
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("vqa_wgrad", dt(dtype), loader, ptr(dy), ptr(x), ptr(dw), M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad)
+    if PROFILE is not None:
+        e1.record()
+        big = N >= 128 and ((C % 128 == 0) if R * S > 1 else (Kw >= 128)) and loader == LOADER_NHWC
+        t = 128 if big else 64
+        PROFILE.append((f"wgrad_kernel<{_tname(dtype)}, {t}, {t}, {loader}>", 2.0 * M * N * Kw, e0, e1))
 
 
 def linear_geom(M, K):

@@ -1,0 +1,83 @@
+"""Data-parallel train-step harness (this repo's counterpart of Trainer.train_epoch, reference
+training/train.py:168-208, non-AMP branch): zero_grad -> forward -> CrossEntropyLoss(mean) -> backward ->
+[RCCL all-reduce of gradient buckets, overlapped with the remaining backward] -> clip_grad_norm_(1.0) -> AdamW.
+
+Everything runs on device with no host synchronisation inside a step: the loss stays a device scalar, the
+global gradient norm is consumed by the AdamW kernel straight from device memory.
+One process per GPU; gradients are summed over ranks with torch.distributed (backend "nccl" = RCCL over xGMI,
+or "gloo" in the CPU rehearsal tests) and divided by world size inside the optimizer kernel.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import layout as LY
+from ._lib import call, dt, ptr
+
+
+class HipTrainer:
+    def __init__(self, model, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
+                 process_group=None, overlap=True):
+        self.model = model
+        self.engine = model._ensure_engine()
+        self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_grad_norm
+        flat = model._flat
+        self.G = torch.zeros_like(flat)
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.sumsq = torch.zeros(1, device=flat.device, dtype=torch.float32)
+        self.loss = torch.zeros(1, device=flat.device, dtype=torch.float32)
+        self.t = 0
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.pg = process_group
+        self.overlap = overlap
+        self.buckets = LY.bucket_ranges(model._entries)
+        self._bucket_of = {name: (lo, hi) for name, lo, hi in self.buckets}
+        self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
+        self._works: List = []
+
+    # gradient bucket all-reduce, issued as soon as the segment's last gradient kernel is enqueued
+    def _on_segment(self, name: str):
+        if self.world == 1 or name not in self._bucket_of:
+            return
+        lo, hi = self._bucket_of[name]
+        bucket = self.G[lo:hi]
+        if self.overlap:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def step(self, images, token_ids, attention_mask, targets):
+        """One full train step; returns (loss device scalar, logits fp32)."""
+        eng, T = self.engine, self.engine.dtype
+        self.G.zero_()
+        self.sumsq.zero_()
+        self.loss.zero_()
+        maskf = None if attention_mask is None else attention_mask.float()
+        logits_f, _, tape = eng.forward(images, token_ids, maskf, True, False, need_tape=True)
+        B, N = logits_f.shape
+        dlogits = torch.empty((B, N), device=images.device, dtype=torch.float32)
+        call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0)
+        self._works = []
+        eng.backward(tape, dlogits, self.G, on_segment=self._on_segment)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        gscale = 1.0 / self.world
+        call("vqa_sumsq", ptr(self.G), self.G.numel(), ptr(self.sumsq))
+        self.t += 1
+        b1, b2 = self.betas
+        call("vqa_adamw", ptr(self.model._flat), ptr(self.G), ptr(self.m), ptr(self.v), self.G.numel(), self.lr, b1, b2, self.eps,
+             self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, ptr(self.sumsq), float(self.max_norm), gscale)
+        eng.step_id += 1
+        return self.loss, logits_f
+
+    def grad_norm(self) -> torch.Tensor:
+        return self.sumsq.sqrt() / self.world
