@@ -1,0 +1,124 @@
+/* libvqa_hip.so -- C ABI of the MI355X (gfx950) VQA forward/backward kernels.
+ *
+ * Conventions:
+ *   - raw DEVICE pointers + explicit sizes + a hipStream_t; the caller (PyTorch) owns every buffer, including
+ *     workspaces and tensors saved for backward; functions never allocate, never synchronise, never throw;
+ *   - return value: 0 = launched, 1000 = argument/shape error (nothing launched), otherwise a hipError_t;
+ *   - dtype: 0 = float32 (fp32 MFMA, parity path), 1 = bfloat16 (bf16 MFMA, fp32 accumulate); statistics,
+ *     coefficients, weight gradients and optimizer state are always float32;
+ *   - CNN activations are NHWC, token tensors are [rows][D]; conv weights are [Cout][R][S][Cin];
+ *   - "+=" outputs (weight / bias gradients) accumulate into caller-zeroed fp32 buffers.
+ * Each entry cites the reference interface (path relative to the reference checkout) it replaces.
+ */
+#ifndef VQA_HIP_H
+#define VQA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct ihipStream_t* hipStream_t;
+
+/* ---- implicit-GEMM convolution / linear -------------------------------------------------------------------
+ * Replaces nn.Conv2d forward + its autograd backward (models/cnn_backbone.py:148-158 conv1/conv2, :243-247 shortcut,
+ * :350 stem) and every nn.Linear (models/text_encoder.py:176-179,309-310; models/cross_attention.py:98-101,257-263;
+ * models/fusion.py:68; models/vqa_model.py:74-82).
+ * loader 0: NHWC activations, 1: 7x7/2 stem straight from the NCHW fp32 image.
+ * out[M][N] = gather(a)[M][Kw] * w[N][Kw]^T, then +bias, ReLU, dropout(drop_p, drop_seed), + addend*(addmask>0);
+ * stats != NULL: per-M-tile column sums / sums of squares ([vqa_igemm_mtiles][2][N]) for train-mode BatchNorm.
+ * transposed = 1 gathers for the data gradient (a = dY [B,H,W,C], rows index dX [B,Ho,Wo]). */
+int vqa_igemm_mtiles(int M, int N, int loader);
+int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, const float* bias, const void* addend,
+              const void* addmask, float* stats, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
+              int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
+              hipStream_t stream);
+/* dw[N][Kw] += dy[M][N]^T * gather(x)[M][Kw]   (split over M, fp32 atomics) */
+int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw, int M, int N, int Kw, int B, int H, int W,
+              int C, int Ho, int Wo, int R, int S, int stride, int pad, hipStream_t stream);
+int vqa_pack_rows(int dtype, const float* in, void* out, int N, int K, int Kp, hipStream_t stream);          /* cast + row pad   */
+int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int T, int C, hipStream_t stream);      /* [N][T][C]->[C][T][N] */
+
+/* ---- BatchNorm2d (nn.BatchNorm2d defaults; models/cnn_backbone.py:151,158,246,351) -----------------------------
+ * coef = scale | shift | mean | invstd (4*C floats).  finalize also updates running_mean/var (momentum, unbiased var)
+ * and num_batches_tracked when those pointers are non-NULL. */
+int vqa_bn_stats_finalize(const float* part, int tiles, int C, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                          double* scratch /* >= 64*2*C */, float* coef, hipStream_t stream);
+int vqa_bn_eval_coef(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                     float eps, float* coef, hipStream_t stream);
+/* out = [relu](y*scale+shift [+ res | + res*rscale+rshift])   -- BN + residual add + ReLU (cnn_backbone.py:186-195) */
+int vqa_bn_apply(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, void* out,
+                 long long numel, int C, int relu, hipStream_t stream);
+int vqa_bn_bwd_blocks(long long rows);
+int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const void* y, const float* coef, const void* y2,
+                      const float* coef2, float* slab /* [blocks][3][C] */, long long rows, int C, hipStream_t stream);
+int vqa_bn_bwd_finalize(const float* slab, int nblk, int C, int which, double count, const float* gamma, const float* coef,
+                        int training, float* dgamma, float* dbeta, float* bcoef /* 3*C */, hipStream_t stream);
+int vqa_bn_bwd_apply(int dtype, const void* dout, const void* outact, const void* y, const float* bcoef, void* dy,
+                     const void* y2, const float* bcoef2, void* dy2, long long numel, int C, hipStream_t stream);
+
+/* ---- stem tail: BN + ReLU + MaxPool2d(3,2,1) fused (models/cnn_backbone.py:351-353) ----------------------------- */
+int vqa_stem_pool_fwd(int dtype, const void* y, const float* coef, void* out, uint8_t* idx, int B, int H, int W, int C, hipStream_t stream);
+int vqa_stem_bwd_reduce(int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* coef, float* slab,
+                        int B, int H, int W, int C, hipStream_t stream);
+int vqa_stem_bwd_apply(int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* coef, const float* bcoef,
+                       void* dy, int B, int H, int W, int C, hipStream_t stream);
+
+/* ---- SEAttention.forward (models/attention_modules.py:109-136) and its backward ---------------------------------- */
+int vqa_se_fwd(int dtype, const void* x, const float* w1, const float* w2, float* pooled, float* hidden, float* scale,
+               void* out, int B, int HW, int C, int Cr, hipStream_t stream);
+int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, const float* w2, const float* pooled,
+               const float* hidden, const float* scale, float* scratch /* B*(2C+Cr) */, void* dx, float* dw1, float* dw2,
+               int B, int HW, int C, int Cr, hipStream_t stream);
+/* ---- SpatialAttention.forward (models/attention_modules.py:223-243) and its backward ----------------------------- */
+int vqa_spatial_fwd(int dtype, const void* x, const float* w /* (1,2,7,7) */, float* pooled2, int* argmax, float* amap,
+                    void* out, int B, int H, int W, int C, hipStream_t stream);
+int vqa_spatial_bwd(int dtype, const void* dout, const void* x, const float* w, const float* pooled2, const int* argmax,
+                    const float* amap, float* scratch /* 3*B*H*W */, void* dx, float* dw, int B, int H, int W, int C, hipStream_t stream);
+int vqa_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int HW, int C, hipStream_t stream);   /* aux['image_features'] */
+int vqa_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int HW, int C, hipStream_t stream);
+
+/* ---- token side ------------------------------------------------------------------------------------------------------
+ * embedding*sqrt(d) + sinusoidal PE + dropout (models/text_encoder.py:504-510,112-114); padding_idx 0 gets no gradient */
+int vqa_embed_fwd(int dtype, const long long* ids, const float* emb, const float* pe, void* out, int rows, int L, int D, int V,
+                  float scale, float p, unsigned long long seed, hipStream_t stream);
+int vqa_embed_bwd(int dtype, const long long* ids, const void* dout, float* demb, int rows, int D, int V, float scale, float p,
+                  unsigned long long seed, hipStream_t stream);
+/* nn.LayerNorm(eps 1e-5) (+dropout, + addrow[row % period]: ImageFeatureProjector, models/fusion.py:98-112) */
+int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* mean_rstd, int rows, int D,
+                      float eps, float p, unsigned long long seed, const float* addrow, int period, hipStream_t stream);
+int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* gamma, const float* mean_rstd, const void* addend,
+                      void* dx, float* dgamma, float* dbeta, int rows, int D, float p, unsigned long long seed, float* dadd,
+                      int period, hipStream_t stream);
+/* softmax(QK^T/sqrt(hd) [keys with kmask==0 -> -inf]) (dropout) V, one wave per (batch, head)
+ * (models/text_encoder.py:237-258, models/cross_attention.py:176-198); probs = softmax before dropout [B][H][Lq][Lk] */
+int vqa_attention_fwd(int dtype, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const float* kmask,
+                      float* probs, void* ctx, int ldc, int B, int H, int Lq, int Lk, int hd, float p, unsigned long long seed,
+                      hipStream_t stream);
+int vqa_attention_bwd(int dtype, const void* dctx, int ldc, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
+                      const float* probs, void* dq, void* dk, void* dv, int lddq, int lddk, int lddv, int B, int H, int Lq, int Lk,
+                      int hd, float p, unsigned long long seed, hipStream_t stream);
+/* masked mean over tokens (models/fusion.py:303-313, models/text_encoder.py:522-527) */
+int vqa_masked_pool_fwd(int dtype, const void* x, const float* mask, void* out, int ldo, int col0, int B, int L, int D, hipStream_t stream);
+int vqa_masked_pool_bwd(int dtype, const void* dpool, int ldo, int col0, const float* mask, const void* addend, void* dx,
+                        int B, int L, int D, hipStream_t stream);
+/* GatingMechanism.forward (models/fusion.py:160-166): fused = g*att + (1-g)*txt, g = sigmoid(z), cat = [att|txt] */
+int vqa_gate_fwd(int dtype, const void* z, const void* cat, void* fused, int B, int D, hipStream_t stream);
+int vqa_gate_bwd(int dtype, const void* dfused, const void* z, const void* cat, void* dz, void* dcat, int B, int D, hipStream_t stream);
+int vqa_add(int dtype, const void* a, const void* b, void* out, long long n, hipStream_t stream);
+/* gradient at the pre-activation of linear(+bias)(+ReLU)(+dropout); dbias += column sums */
+int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, float* dbias, int M, int N, float p,
+                     unsigned long long seed, hipStream_t stream);
+/* nn.CrossEntropyLoss() mean (training/train.py:120): loss += mean NLL, dlogits = (softmax-onehot)*gscale/B */
+int vqa_cross_entropy(int dtype, const void* logits, const long long* targets, float* loss, void* dlogits, float* logits_f32,
+                      int B, int N, float gscale, hipStream_t stream);
+int vqa_convert(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
+/* clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (training/train.py:204-208,127-132) */
+int vqa_sumsq(const float* g, long long n, float* out, hipStream_t stream);
+int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, float bias_corr1, float bias_corr2, const float* sumsq, float max_norm, float gscale,
+              hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,55 @@
+"""CPU rehearsal of the N>1 path: two gloo ranks run the bucketed gradient all-reduce of trainer.GradBucketReducer over
+the real bucket table, in backward-completion order, and must end with the mean-able sum on every rank."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from _pkg import sub
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import vqa_oracle as O
+    LY, TR = sub("layout"), sub("trainer")
+    ent = LY.build_entries(O.full_config(embed_dim=32, vocab_size=100, num_answers=10))
+    n = LY.flat_size(ent)
+    g = torch.Generator().manual_seed(100 + rank)
+    G = torch.randn(n, generator=g)
+    mine = G.clone()
+    red = TR.GradBucketReducer(G, LY.bucket_ranges(ent))
+    order = []
+    for name, _, _ in red.buckets:            # the engine calls on_segment in exactly this order
+        red.on_segment(name)
+        order.append(name)
+    scale = red.finish()
+    others = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    expect = sum(others)
+    ok = torch.allclose(G, expect, atol=1e-6) and abs(scale - 1.0 / world) < 1e-12 and not torch.equal(G, mine)
+    q.put((rank, bool(ok), order))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2][0] == "answer_head" and res[0][2][-1] == "image_encoder.stem"

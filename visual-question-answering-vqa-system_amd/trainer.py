@@ -18,6 +18,45 @@ from . import layout as LY
 from ._lib import call, dt, ptr
 
 
+class GradBucketReducer:
+    """Sum-all-reduce of contiguous gradient buckets, issued bucket by bucket while backward is still running.
+    Device-agnostic (CUDA tensors: side stream + events, RCCL; CPU tensors: gloo) so the N>1 logic is testable on CPU."""
+
+    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, overlap=True):
+        self.G = flat_grad
+        self.buckets = list(buckets)
+        self._range = {name: (lo, hi) for name, lo, hi in self.buckets}
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.overlap = overlap and flat_grad.is_cuda
+        self.comm_stream = torch.cuda.Stream() if (self.world > 1 and self.overlap) else None
+        self._works: List = []
+        self.issued: List[str] = []
+
+    def on_segment(self, name: str):
+        if self.world == 1 or name not in self._range:
+            return
+        lo, hi = self._range[name]
+        bucket = self.G[lo:hi]
+        self.issued.append(name)
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        """Make the current stream (or the host, for gloo) wait for every bucket; returns the 1/world gradient scale."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self.issued = []
+        return 1.0 / self.world
+
+
 class HipTrainer:
     def __init__(self, model, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  process_group=None, overlap=True):
@@ -31,28 +70,9 @@ class HipTrainer:
         self.sumsq = torch.zeros(1, device=flat.device, dtype=torch.float32)
         self.loss = torch.zeros(1, device=flat.device, dtype=torch.float32)
         self.t = 0
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.pg = process_group
-        self.overlap = overlap
         self.buckets = LY.bucket_ranges(model._entries)
-        self._bucket_of = {name: (lo, hi) for name, lo, hi in self.buckets}
-        self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
-        self._works: List = []
-
-    # gradient bucket all-reduce, issued as soon as the segment's last gradient kernel is enqueued
-    def _on_segment(self, name: str):
-        if self.world == 1 or name not in self._bucket_of:
-            return
-        lo, hi = self._bucket_of[name]
-        bucket = self.G[lo:hi]
-        if self.overlap:
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
-                self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-        else:
-            self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self.reducer = GradBucketReducer(self.G, self.buckets, process_group, overlap)
+        self.world = self.reducer.world
 
     def step(self, images, token_ids, attention_mask, targets):
         """One full train step; returns (loss device scalar, logits fp32)."""
@@ -65,12 +85,8 @@ class HipTrainer:
         B, N = logits_f.shape
         dlogits = torch.empty((B, N), device=images.device, dtype=torch.float32)
         call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0)
-        self._works = []
-        eng.backward(tape, dlogits, self.G, on_segment=self._on_segment)
-        for w in self._works:
-            w.wait()
-        self._works = []
-        gscale = 1.0 / self.world
+        eng.backward(tape, dlogits, self.G, on_segment=self.reducer.on_segment)
+        gscale = self.reducer.finish()
         call("vqa_sumsq", ptr(self.G), self.G.numel(), ptr(self.sumsq))
         self.t += 1
         b1, b2 = self.betas
