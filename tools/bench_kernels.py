@@ -1,0 +1,54 @@
+"""Micro-benchmark of the GEMM-class kernels on the layer shapes of the B=512 train step (not part of the product)."""
+import argparse
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("visual-question-answering-vqa-system_amd")
+K = pkg.kernels
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--only", default="")
+args = ap.parse_args()
+B, T, dev = args.batch, torch.bfloat16, "cuda"
+
+# (name, Cin, Cout, H, R, stride, pad)
+CONVS = [("s1 3x3 64->64 56", 64, 64, 56, 3, 1, 1), ("s2a 3x3/2 64->128", 64, 128, 56, 3, 2, 1), ("s2 3x3 128->128 28", 128, 128, 28, 3, 1, 1),
+         ("s3 3x3 256->256 14", 256, 256, 14, 3, 1, 1), ("s4 3x3 512->512 7", 512, 512, 7, 3, 1, 1), ("s3a 3x3/2 128->256", 128, 256, 28, 3, 2, 1)]
+
+
+def timeit(fn, iters):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+for name, Cin, Cout, H, R, stride, pad in CONVS:
+    if args.only and args.only not in name:
+        continue
+    Ho = (H + 2 * pad - R) // stride + 1
+    x = torch.randn(B * H * H, Cin, device=dev).to(T)
+    w = (torch.randn(Cout, R * R * Cin, device=dev) * 0.05)
+    dy = torch.randn(B * Ho * Ho, Cout, device=dev).to(T)
+    wp = K.pack_rows(w, T)
+    wt = K.pack_transpose(w.view(Cout, R * R, Cin), T)
+    M, Kw = B * Ho * Ho, R * R * Cin
+    geom = (B, H, H, Cin, Ho, Ho, R, R, stride, pad)
+    geom_d = (B, Ho, Ho, Cout, H, H, R, R, stride, pad)
+    dw = torch.zeros(Cout, Kw, device=dev)
+    fl = 2.0 * M * Cout * Kw
+    t = timeit(lambda: K.igemm(x, wp, M, Cout, Kw, geom, dtype=T, want_stats=True), args.iters)
+    print(f"{name:22s} fwd   {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   io {(x.numel()+M*Cout)*2/t/1e12:5.2f} TB/s")
+    t = timeit(lambda: K.igemm(dy, wt, B * H * H, Cin, R * R * Cout, geom_d, dtype=T, transposed=1), args.iters)
+    print(f"{name:22s} dgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: K.wgrad(dy, x, dw, M, Cout, Kw, geom, dtype=T), args.iters)
+    print(f"{name:22s} wgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")

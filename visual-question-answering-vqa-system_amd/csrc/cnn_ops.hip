@@ -60,22 +60,31 @@ __global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta
   coef[c] = sc; coef[C + c] = beta[c] - rm[c] * sc; coef[2 * C + c] = rm[c]; coef[3 * C + c] = invstd;
 }
 
-// out = [relu]( y*scale+shift  [+ res*rscale+rshift | + res] )
+// out = [relu]( y*scale+shift  [+ res*rscale+rshift | + res] ).  Each thread owns one 16-byte channel vector
+// (coefficients stay in registers) and walks rows; a block covers 256/cv consecutive rows = one contiguous span.
 template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ coef, const T* __restrict__ res,
-                                const float* __restrict__ rcoef, T* __restrict__ out, size_t nvec, int C, int relu) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ coef, const T* __restrict__ res,
+                                const float* __restrict__ rcoef, T* __restrict__ out, size_t rows, int C, int relu) {
   constexpr int VEC = Vec16<T>::N;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)((i * VEC) % C);
-    Vec16<T> v = ldg16(y + i * VEC), r, o;
-    if (res) r = ldg16(res + i * VEC);
+  const int cv = C / VEC, lanes_r = 256 / cv;
+  const int c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
+  float sc[VEC], sh[VEC], rs[VEC], rh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = coef[c0 + j]; sh[j] = coef[C + c0 + j];
+    rs[j] = rcoef ? rcoef[c0 + j] : 1.f; rh[j] = rcoef ? rcoef[C + c0 + j] : 0.f;
+  }
+  for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
+    const size_t off = r * C + c0;
+    Vec16<T> v = ldg16(y + off), rr, o;
+    if (res) rr = ldg16(res + off);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      float x = v.get(j) * coef[c0 + j] + coef[C + c0 + j];
-      if (res) x += rcoef ? (r.get(j) * rcoef[c0 + j] + rcoef[C + c0 + j]) : r.get(j);
+      float x = v.get(j) * sc[j] + sh[j];
+      if (res) x += rr.get(j) * rs[j] + rh[j];
       o.set(j, (relu && x < 0.f) ? 0.f : x);   // NaN-propagating ReLU like torch
     }
-    stg16(out + i * VEC, o);
+    stg16(out + off, o);
   }
 }
 
@@ -129,13 +138,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 
 // reduce slab over blocks; emit dgamma/dbeta (+=) and the apply coefficients  dy = A*g + Bc*y + Cc
 // bcoef layout (3*C): A | Bc | Cc
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nblk, int C, int which, double count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nblk, int C, int which, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ coef, int training,
                                        float* dgamma, float* dbeta, float* __restrict__ bcoef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), tl = threadIdx.x >> 6;
+  __shared__ double sh[2][4][64];
   double sg = 0.0, sx = 0.0;
-  for (int b = 0; b < nblk; ++b) { sg += slab[((size_t)b * 3) * C + c]; sx += slab[((size_t)b * 3 + which) * C + c]; }
+  if (c < C)
+    for (int b = tl; b < nblk; b += 4) { sg += slab[((size_t)b * 3) * C + c]; sx += slab[((size_t)b * 3 + which) * C + c]; }
+  sh[0][tl][threadIdx.x & 63] = sg; sh[1][tl][threadIdx.x & 63] = sx;
+  __syncthreads();
+  if (tl != 0 || c >= C) return;
+  for (int i = 1; i < 4; ++i) { sg += sh[0][i][threadIdx.x]; sx += sh[1][i][threadIdx.x]; }
   if (dgamma) dgamma[c] += (float)sx;
   if (dbeta) dbeta[c] += (float)sg;
   const float mean = coef[2 * C + c], invstd = coef[3 * C + c], gi = gamma[c] * invstd;
@@ -147,24 +161,32 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nblk,
 
 // dy = A*g + B*y + C ; optional second output dy2 = A2*g + B2*y2 + C2 ; optional gout = g (T) for the identity path
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ outact, const T* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ outact, const T* __restrict__ y,
                                     const float* __restrict__ bc, T* __restrict__ dy, const T* __restrict__ y2,
-                                    const float* __restrict__ bc2, T* __restrict__ dy2, size_t nvec, int C) {
+                                    const float* __restrict__ bc2, T* __restrict__ dy2, size_t rows, int C) {
   constexpr int VEC = Vec16<T>::N;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)((i * VEC) % C);
-    Vec16<T> d = ldg16(dout + i * VEC), yy = ldg16(y + i * VEC), o, y2v, r, r2;
-    if (outact) o = ldg16(outact + i * VEC);
-    if (y2) y2v = ldg16(y2 + i * VEC);
+  const int cv = C / VEC, lanes_r = 256 / cv;
+  const int c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
+  float a[VEC], b[VEC], c[VEC], a2[VEC], b2[VEC], c2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    a[j] = bc[c0 + j]; b[j] = bc[C + c0 + j]; c[j] = bc[2 * C + c0 + j];
+    a2[j] = y2 ? bc2[c0 + j] : 0.f; b2[j] = y2 ? bc2[C + c0 + j] : 0.f; c2[j] = y2 ? bc2[2 * C + c0 + j] : 0.f;
+  }
+  for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
+    const size_t off = r * C + c0;
+    Vec16<T> d = ldg16(dout + off), yy = ldg16(y + off), o, y2v, rr, r2;
+    if (outact) o = ldg16(outact + off);
+    if (y2) y2v = ldg16(y2 + off);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float g = d.get(j);
       if (outact && !(o.get(j) > 0.f)) g = 0.f;
-      r.set(j, bc[c0 + j] * g + bc[C + c0 + j] * yy.get(j) + bc[2 * C + c0 + j]);
-      if (y2) r2.set(j, bc2[c0 + j] * g + bc2[C + c0 + j] * y2v.get(j) + bc2[2 * C + c0 + j]);
+      rr.set(j, a[j] * g + b[j] * yy.get(j) + c[j]);
+      if (y2) r2.set(j, a2[j] * g + b2[j] * y2v.get(j) + c2[j]);
     }
-    stg16(dy + i * VEC, r);
-    if (y2) stg16(dy2 + i * VEC, r2);
+    stg16(dy + off, rr);
+    if (y2) stg16(dy2 + off, r2);
   }
 }
 
@@ -417,16 +439,18 @@ __global__ void se_bwd_apply_kernel(const T* __restrict__ dout, const float* __r
 }
 
 // dw2[c][j] += sum_b dz2[b][c]*hidden[b][j] ; dw1[j][c] += sum_b dh[b][j]*pooled[b][c]
-__global__ void se_wgrad_kernel(const float* __restrict__ dz2, const float* __restrict__ hidden, const float* __restrict__ dh,
+__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ dz2, const float* __restrict__ hidden, const float* __restrict__ dh,
                                 const float* __restrict__ pooled, float* dw1, float* dw2, int B, int C, int Cr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (i >= C * Cr) return;
-  { const int c = i / Cr, j = i - c * Cr; float t = 0.f;
-    for (int b = 0; b < B; ++b) t += dz2[(size_t)b * C + c] * hidden[(size_t)b * Cr + j];
-    dw2[i] += t; }
-  { const int j = i / C, c = i - j * C; float t = 0.f;
-    for (int b = 0; b < B; ++b) t += dh[(size_t)b * Cr + j] * pooled[(size_t)b * C + c];
-    dw1[i] += t; }
+  float t2 = 0.f, t1 = 0.f;
+  { const int c = i / Cr, j = i - c * Cr;
+    for (int b = lane; b < B; b += 64) t2 += dz2[(size_t)b * C + c] * hidden[(size_t)b * Cr + j]; }
+  { const int j = i / C, c = i - j * C;
+    for (int b = lane; b < B; b += 64) t1 += dh[(size_t)b * Cr + j] * pooled[(size_t)b * C + c]; }
+  t2 = wave_sum(t2); t1 = wave_sum(t1);
+  if (lane == 0) { dw2[i] += t2; dw1[i] += t1; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -561,6 +585,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
 // C ABI
 // ---------------------------------------------------------------------------------------------
 static inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 16384 ? 16384 : (g ? g : 1)); }
+static inline int row_grid(size_t rows, int lanes_r) { size_t g = (rows + lanes_r - 1) / lanes_r; return (int)(g > 8192 ? 8192 : (g ? g : 1)); }
 #define DT(call_f, call_b) do { if (dtype) { call_b; } else { call_f; } } while (0)
 
 extern "C" {
@@ -582,10 +607,11 @@ int vqa_bn_eval_coef(int C, const float* gamma, const float* beta, const float* 
 }
 int vqa_bn_apply(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, void* out, long long numel, int C, int relu, hipStream_t st) {
   const int VEC = dtype ? 8 : 4;
-  if (C % VEC || numel % C) return VQA_EARG;
-  const size_t nvec = (size_t)numel / VEC;
-  DT(hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)y, coef, (const float*)res, rcoef, (float*)out, nvec, C, relu),
-     hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)y, coef, (const bf16_t*)res, rcoef, (bf16_t*)out, nvec, C, relu));
+  if (C % VEC || numel % C || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  const size_t rows = (size_t)numel / C;
+  const int grid = row_grid(rows, 256 / (C / VEC));
+  DT(hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, coef, (const float*)res, rcoef, (float*)out, rows, C, relu),
+     hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)y, coef, (const bf16_t*)res, rcoef, (bf16_t*)out, rows, C, relu));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_bn_bwd_blocks(long long rows) { long long g = (rows + 63) / 64; return (int)(g > 1024 ? 1024 : (g < 1 ? 1 : g)); }
@@ -602,16 +628,17 @@ int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const voi
 }
 int vqa_bn_bwd_finalize(const float* slab, int nblk, int C, int which, double count, const float* gamma, const float* coef, int training,
                         float* dgamma, float* dbeta, float* bcoef, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, slab, nblk, C, which, count, gamma, coef, training, dgamma, dbeta, bcoef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, nblk, C, which, count, gamma, coef, training, dgamma, dbeta, bcoef);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_bn_bwd_apply(int dtype, const void* dout, const void* outact, const void* y, const float* bc, void* dy,
                      const void* y2, const float* bc2, void* dy2, long long numel, int C, hipStream_t st) {
   const int VEC = dtype ? 8 : 4;
-  if (C % VEC || numel % C) return VQA_EARG;
-  const size_t nvec = (size_t)numel / VEC;
-  DT(hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)dout, (const float*)outact, (const float*)y, bc, (float*)dy, (const float*)y2, bc2, (float*)dy2, nvec, C),
-     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (const bf16_t*)y, bc, (bf16_t*)dy, (const bf16_t*)y2, bc2, (bf16_t*)dy2, nvec, C));
+  if (C % VEC || numel % C || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  const size_t rows = (size_t)numel / C;
+  const int grid = row_grid(rows, 256 / (C / VEC));
+  DT(hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)outact, (const float*)y, bc, (float*)dy, (const float*)y2, bc2, (float*)dy2, rows, C),
+     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (const bf16_t*)y, bc, (bf16_t*)dy, (const bf16_t*)y2, bc2, (bf16_t*)dy2, rows, C));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 
@@ -664,7 +691,7 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   const size_t nvec = (size_t)B * HW * C / VEC;
   DT(hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)dout, scale, dpool, (float*)dx, nvec, HW, C),
      hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)dout, scale, dpool, (bf16_t*)dx, nvec, HW, C));
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 255) / 256), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 3) / 4), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 
