@@ -35,7 +35,15 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
 int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw, int M, int N, int Kw, int B, int H, int W,
               int C, int Ho, int Wo, int R, int S, int stride, int pad, hipStream_t stream);
 int vqa_pack_rows(int dtype, const float* in, void* out, int N, int K, int Kp, hipStream_t stream);          /* cast + row pad   */
-int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int T, int C, hipStream_t stream);      /* [N][T][C]->[C][T][N] */
+int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int T, int C, int ldo, int col0, hipStream_t stream); /* out[c][col0+t*N+n] */
+/* data gradient of a stride-2 conv (+ the block's 1x1/2 shortcut, models/cnn_backbone.py:243-247) in one launch; rows are
+ * grouped by output parity class so only the valid taps are issued.  dy/dyd [B][H][W][C], out [B][Ho=2H][Wo=2W][N] */
+int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, void* out, int B, int H, int W, int C,
+                 int Ho, int Wo, int N, int R, int pad, hipStream_t stream);
+/* dedicated bf16 stem conv 7x7/2 (models/cnn_backbone.py:350): image patch + weights resident in LDS */
+int vqa_stem_conv_blocks(int B, int H, int W);
+int vqa_stem_pack(const float* w_krsc, void* wstem, hipStream_t stream);
+int vqa_stem_conv(const float* img, const void* wstem, void* out, float* stats, int B, int H, int W, hipStream_t stream);
 
 /* ---- BatchNorm2d (nn.BatchNorm2d defaults; models/cnn_backbone.py:151,158,246,351) -----------------------------
  * coef = scale | shift | mean | invstd (4*C floats).  finalize also updates running_mean/var (momentum, unbiased var)

@@ -136,3 +136,53 @@ def test_stem_conv_fwd_wgrad(dtype):
     K.wgrad(dy.permute(0, 2, 3, 1).contiguous().to(DEV, dtype), img.to(DEV), dw, M, 64, 147, geom, dtype=dtype, loader=K.LOADER_STEM)
     torch.cuda.synchronize()
     assert _relerr(dw.cpu(), wr.grad.permute(0, 2, 3, 1).reshape(64, 147)) < (2e-4 if dtype == torch.float32 else 3e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 64, 128, 16, True), (3, 128, 256, 12, True), (2, 256, 512, 14, False)])
+def test_stride2_dgrad_by_parity_classes(case, dtype):
+    """conv3x3/2 (+1x1/2 shortcut) data gradient in one launch == autograd of the two ATen convs."""
+    K = sub("kernels")
+    B, Cin, Cout, H, shortcut = case
+    g = torch.Generator().manual_seed(Cin + H)
+    w1 = _round(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05, dtype)
+    wd = _round(torch.randn(Cout, Cin, 1, 1, generator=g) * 0.05, dtype)
+    Ho = H // 2
+    dy = _round(torch.randn(B, Cout, Ho, Ho, generator=g), dtype)
+    dyd = _round(torch.randn(B, Cout, Ho, Ho, generator=g), dtype)
+    x = torch.zeros(B, Cin, H, H, requires_grad=True)
+    out = (F.conv2d(x, w1, None, stride=2, padding=1) * dy).sum()
+    if shortcut:
+        out = out + (F.conv2d(x, wd, None, stride=2, padding=0) * dyd).sum()
+    out.backward()
+    ktot = (10 if shortcut else 9) * Cout
+    wt = torch.empty(Cin, ktot, device=DEV, dtype=dtype)
+    K.pack_transpose(w1.permute(0, 2, 3, 1).contiguous().to(DEV).view(Cout, 9, Cin), dtype, out=wt, ldo=ktot, col0=0)
+    if shortcut:
+        K.pack_transpose(wd.permute(0, 2, 3, 1).contiguous().to(DEV).view(Cout, 1, Cin), dtype, out=wt, ldo=ktot, col0=9 * Cout)
+    dx = K.dgrad_s2(dy.permute(0, 2, 3, 1).contiguous().to(DEV, dtype), dyd.permute(0, 2, 3, 1).contiguous().to(DEV, dtype) if shortcut else None,
+                    wt, B, Ho, Ho, Cout, H, H, Cin, 3, 1, dtype=dtype)
+    torch.cuda.synchronize()
+    ref = x.grad.permute(0, 2, 3, 1).reshape(B * H * H, Cin)
+    assert _relerr(dx.float().cpu(), ref) < _tol(dtype)
+
+
+@pytest.mark.parametrize("hw", [(224, 224), (64, 64), (96, 160)])
+def test_stem_conv_bf16_dedicated_kernel(hw):
+    K = sub("kernels")
+    H, W = hw
+    B = 2
+    g = torch.Generator().manual_seed(H)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = _round(torch.randn(64, 3, 7, 7, generator=g) * 0.1, torch.bfloat16)
+    ref = F.conv2d(_round(img, torch.bfloat16), w, None, stride=2, padding=3)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    assert K.stem_conv_blocks(B, H, W) == B * Ho // 4
+    wst = torch.empty(64, 192, device=DEV, dtype=torch.bfloat16)
+    sub("_lib").call("vqa_stem_pack", w.permute(0, 2, 3, 1).contiguous().to(DEV).data_ptr(), wst.data_ptr())
+    y, stats, nb = K.stem_conv(img.to(DEV), wst, B, H, W, True)
+    torch.cuda.synchronize()
+    y_ref = ref.permute(0, 2, 3, 1).reshape(-1, 64)
+    assert _relerr(y.float().cpu(), y_ref) < 1.2e-2
+    s = stats.sum(0).cpu()
+    assert _relerr(s[0], y_ref.sum(0)) < 5e-3 and _relerr(s[1], (y_ref ** 2).sum(0)) < 5e-3

@@ -21,7 +21,11 @@ SIGNATURES = {
     "vqa_igemm": [I, I, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, P],
     "vqa_wgrad": [I, I, P, P, P] + [I] * 13 + [P],
     "vqa_pack_rows": [I, P, P, I, I, I, P],
-    "vqa_pack_transpose": [I, P, P, I, I, I, P],
+    "vqa_pack_transpose": [I, P, P, I, I, I, I, I, P],
+    "vqa_dgrad_s2": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "vqa_stem_conv_blocks": [I, I, I],
+    "vqa_stem_pack": [P, P, P],
+    "vqa_stem_conv": [P, P, P, P, I, I, I, P],
     "vqa_bn_stats_finalize": [P, I, I, D, P, P, P, P, P, F, F, P, P, P],
     "vqa_bn_eval_coef": [I, P, P, P, P, F, P, P],
     "vqa_bn_apply": [I, P, P, P, P, P, LL, I, I, P],
@@ -55,7 +59,7 @@ SIGNATURES = {
     "vqa_sumsq": [P, LL, P, P],
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P],
 }
-_NO_STATUS = {"vqa_igemm_mtiles", "vqa_bn_bwd_blocks"}   # return a count, not a status
+_NO_STATUS = {"vqa_igemm_mtiles", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks"}   # return a count, not a status
 
 _lib = None
 

@@ -13,7 +13,7 @@
 // (wgrad reads its operands with ds_read_b64_tr_b16 so the contraction index ends up lane-contiguous).
 #include "common.h"
 
-enum { LOADER_NHWC = 0, LOADER_STEM = 1 };
+enum { LOADER_NHWC = 0, LOADER_STEM = 1, LOADER_DGRAD2 = 2 };
 
 struct IGemmParams {
   const void* a; const void* w; void* out;
@@ -23,6 +23,9 @@ struct IGemmParams {
   int Ho, Wo;                // spatial dims of the GEMM rows (M = B*Ho*Wo)
   int R, S, stride, pad, transposed, relu;
   float drop_p; unsigned long long drop_seed;   // dropout applied after bias/relu, before the addend
+  // LOADER_DGRAD2 (data gradient of a stride-2 conv, rows grouped by output parity class so only valid taps are issued):
+  const void* a2;                               // second source (dY of the 1x1 shortcut), same geometry as a
+  int ntaps[4]; int tap_koff[4][5]; int tap_dh[4][5]; int tap_dw[4][5]; int tap_src[4][5];
 };
 
 template <typename T> struct GT;
@@ -96,17 +99,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int tile_m = blockIdx.x / tiles_n;
+  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  const int n0 = tile_n * BN;
   const int vec = tid & 7, rbase = tid >> 3;
   const T* aT = reinterpret_cast<const T*>(p.a);
+  const T* a2T = reinterpret_cast<const T*>(p.a2);
   const float* aImg = reinterpret_cast<const float*>(p.a);
   const T* wT = reinterpret_cast<const T*>(p.w);
+  // DGRAD2: rows are (class, b, h/2, w/2); a tile never straddles two parity classes
+  const int Hh = p.Ho >> 1, Wh = p.Wo >> 1, class_rows = p.B * Hh * Wh;
+  int cls = 0;
+  if (LOADER == LOADER_DGRAD2) {
+    const int tpc = (class_rows + BM - 1) / BM;
+    cls = tile_m / tpc; tile_m -= cls * tpc;
+  }
+  const int m0 = tile_m * BM;
+  const int row_limit = (LOADER == LOADER_DGRAD2) ? class_rows : p.M;
 
   RowInfo ri[AV];
 #pragma unroll
-  for (int i = 0; i < AV; ++i)
-    ri[i] = decode_row(m0 + rbase + 32 * i, p.M, p.Ho * p.Wo, p.Wo, p.H * p.W, p.stride, p.pad, p.transposed, LOADER == LOADER_STEM);
+  for (int i = 0; i < AV; ++i) {
+    if (LOADER == LOADER_DGRAD2) {
+      const int r = m0 + rbase + 32 * i;
+      if (r >= class_rows) { ri[i].pix = -1; ri[i].ih0 = 0; ri[i].iw0 = 0; }
+      else { const int b = r / (Hh * Wh), rem = r - b * Hh * Wh; ri[i].pix = b * p.H * p.W; ri[i].ih0 = rem / Wh; ri[i].iw0 = rem - ri[i].ih0 * Wh; }
+    } else {
+      ri[i] = decode_row(m0 + rbase + 32 * i, p.M, p.Ho * p.Wo, p.Wo, p.H * p.W, p.stride, p.pad, p.transposed, LOADER == LOADER_STEM);
+    }
+  }
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -115,12 +136,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   Vec16<T> ra[AV], rb[BV];
-  const int nk = p.Kp / BK;
+  const int cpb = p.C / BK;                       // K steps per tap (DGRAD2)
+  const int nk = (LOADER == LOADER_DGRAD2) ? p.ntaps[cls] * cpb : p.Kp / BK;
   const int taps = p.R * p.S;
 
   auto gload = [&](int kt) {
-    const int k0 = kt * BK;
-    if (LOADER == LOADER_NHWC) {
+    int k0 = kt * BK;
+    if (LOADER == LOADER_DGRAD2) {
+      const int t = kt / cpb, c0 = (kt - t * cpb) * BK + vec * VEC;
+      const int dh = p.tap_dh[cls][t], dw = p.tap_dw[cls][t];
+      const T* src = p.tap_src[cls][t] ? a2T : aT;
+      k0 = p.tap_koff[cls][t] + (kt - t * cpb) * BK;
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        const int ih = ri[i].ih0 + dh, iw = ri[i].iw0 + dw;
+        const bool ok = ri[i].pix >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        ra[i] = ok ? ldg16(src + ((size_t)(ri[i].pix + ih * p.W + iw)) * p.C + c0) : zero16<T>();
+      }
+    } else if (LOADER == LOADER_NHWC) {
       int tap = 0, c0 = k0;
       if (taps > 1) { tap = k0 / p.C; c0 = k0 - tap * p.C; }
       const int r = tap / p.S, s = tap - r * p.S;
@@ -177,8 +210,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     }
   };
 
-  gload(0);
-  sstore(0);
+  if (nk > 0) { gload(0); sstore(0); }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) gload(kt + 1);
@@ -260,8 +292,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   const T* mskT = reinterpret_cast<const T*>(p.addmask);
   const bool vec_ok = (p.N % VEC) == 0;
   for (int row = tid / VR; row < BM; row += RP) {
-    const int m = m0 + row, n = n0 + (tid % VR) * VEC;
-    if (m >= p.M || n >= p.N) continue;
+    int m = m0 + row;
+    const int n = n0 + (tid % VR) * VEC;
+    if (m >= row_limit || n >= p.N) continue;
+    if (LOADER == LOADER_DGRAD2) {
+      const int b = m / (Hh * Wh), rem = m - b * Hh * Wh, hh = rem / Wh, ww = rem - hh * Wh;
+      m = (b * p.Ho + 2 * hh + (cls >> 1)) * p.Wo + 2 * ww + (cls & 1);
+    }
     Vec16<T> v; v.raw = *reinterpret_cast<const u32x4*>(&Cs[row * LDC + (tid % VR) * VEC]);
     const size_t off = (size_t)m * p.N + n;
     if (vec_ok) {
@@ -439,12 +476,12 @@ __global__ void pack_rows_kernel(const float* __restrict__ in, T* __restrict__ o
   out[i] = from_f<T>(k < K ? in[(size_t)n * K + k] : 0.f);
 }
 template <typename T>
-__global__ void pack_transpose_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int TT, int C) {
-  // out[c][t][n] = in[n][t][c]
+__global__ void pack_transpose_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int TT, int C, int ldo, int col0) {
+  // out[c][col0 + t*N + n] = in[n][t][c]   (row stride ldo)
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)N * TT * C) return;
   int n = (int)(i % N); size_t r = i / N; int t = (int)(r % TT); int c = (int)(r / TT);
-  out[i] = from_f<T>(in[((size_t)n * TT + t) * C + c]);
+  out[(size_t)c * ldo + col0 + t * N + n] = from_f<T>(in[((size_t)n * TT + t) * C + c]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -523,8 +560,51 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
   p.a = a; p.w = w; p.out = out; p.bias = bias; p.addend = addend; p.addmask = addmask; p.stats = stats;
   p.M = M; p.N = N; p.Kw = Kw; p.Kp = (Kw + BK - 1) / BK * BK;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-  p.transposed = transposed; p.relu = relu; p.drop_p = drop_p; p.drop_seed = drop_seed;
+  p.transposed = transposed; p.relu = relu; p.drop_p = drop_p; p.drop_seed = drop_seed; p.a2 = nullptr;
+  for (int c = 0; c < 4; ++c) p.ntaps[c] = 0;
   return dtype ? igemm_dispatch<bf16_t>(p, loader, st) : igemm_dispatch<float>(p, loader, st);
+}
+
+// Data gradient of a stride-2 convolution (R x R, pad) [+ the 1x1/2 shortcut's] in one launch, no redundant taps:
+//   dx[B][Ho][Wo][N] = sum_taps dy[B][H][W][C] * wt[N][(r,s,C)]  (+ dyd[B][H][W][C] * wt[N][R*R*C + C]);  Ho = 2H, Wo = 2W.
+// wt rows are [N][Ktot], Ktot = R*R*C (+ C with the shortcut), built with vqa_pack_transpose(ldo = Ktot, col0).
+int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, void* out, int B, int H, int W, int C,
+                 int Ho, int Wo, int N, int R, int pad, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4, BK = dtype ? 64 : 32;
+  if (!dy || !wt || !out || (Ho & 1) || (Wo & 1) || C % BK || N % VEC || R > 3 || R < 1) return VQA_EARG;
+  IGemmParams p;
+  p.a = dy; p.a2 = dyd; p.w = wt; p.out = out; p.bias = nullptr; p.addend = nullptr; p.addmask = nullptr; p.stats = nullptr;
+  p.N = N; p.Kw = R * R * C + (dyd ? C : 0); p.Kp = p.Kw; p.M = B * Ho * Wo;
+  p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = R; p.stride = 2; p.pad = pad;
+  p.transposed = 1; p.relu = 0; p.drop_p = 0.f; p.drop_seed = 0;
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      const int cls = ph * 2 + pw; int nt = 0;
+      for (int r = 0; r < R; ++r) {
+        if ((ph + pad - r) & 1) continue;
+        for (int s = 0; s < R; ++s) {
+          if ((pw + pad - s) & 1) continue;
+          p.tap_koff[cls][nt] = (r * R + s) * C; p.tap_dh[cls][nt] = (ph + pad - r) / 2; p.tap_dw[cls][nt] = (pw + pad - s) / 2;
+          p.tap_src[cls][nt] = 0; ++nt;
+        }
+      }
+      if (dyd && cls == 0) { p.tap_koff[cls][nt] = R * R * C; p.tap_dh[cls][nt] = 0; p.tap_dw[cls][nt] = 0; p.tap_src[cls][nt] = 1; ++nt; }
+      p.ntaps[cls] = nt;
+      for (int t = nt; t < 5; ++t) { p.tap_koff[cls][t] = 0; p.tap_dh[cls][t] = 0; p.tap_dw[cls][t] = 0; p.tap_src[cls][t] = 0; }
+    }
+  const int class_rows = B * (Ho / 2) * (Wo / 2);
+  const int bn = N <= 64 ? 64 : 128;
+  const int tiles = 4 * ((class_rows + 127) / 128) * ((N + bn - 1) / bn);
+  auto go = [&](auto kern, int smem) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, st, p);
+  };
+  if (dtype) { if (bn == 64) go(&igemm_kernel<bf16_t, 128, 64, LOADER_DGRAD2>, IGemmCfg<bf16_t, 128, 64>::SMEM);
+               else go(&igemm_kernel<bf16_t, 128, 128, LOADER_DGRAD2>, IGemmCfg<bf16_t, 128, 128>::SMEM); }
+  else { if (bn == 64) go(&igemm_kernel<float, 128, 64, LOADER_DGRAD2>, IGemmCfg<float, 128, 64>::SMEM);
+         else go(&igemm_kernel<float, 128, 128, LOADER_DGRAD2>, IGemmCfg<float, 128, 128>::SMEM); }
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
 }
 
 int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
@@ -570,13 +650,13 @@ int vqa_pack_rows(int dtype, const float* in, void* out, int N, int K, int Kp, h
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }
-// out[C][T][N] (T) = in[N][T][C] fp32
-int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int TT, int C, hipStream_t st) {
-  if (!in || !out || N <= 0 || TT <= 0 || C <= 0) return VQA_EARG;
+// out[c][col0 + t*N + n] (T, row stride ldo >= col0 + T*N) = in[N][T][C] fp32
+int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int TT, int C, int ldo, int col0, hipStream_t st) {
+  if (!in || !out || N <= 0 || TT <= 0 || C <= 0 || ldo < col0 + TT * N) return VQA_EARG;
   size_t total = (size_t)N * TT * C;
   dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype) hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, N, TT, C);
-  else hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, N, TT, C);
+  if (dtype) hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, N, TT, C, ldo, col0);
+  else hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, N, TT, C, ldo, col0);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }

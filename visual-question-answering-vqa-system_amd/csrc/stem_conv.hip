@@ -1,0 +1,147 @@
+// Stem convolution 7x7 / stride 2 / pad 3, 3 -> 64 channels, bf16 MFMA (reference models/cnn_backbone.py:349-350).
+//
+// One workgroup = one image, RB = 4 consecutive output rows.  The 13 x (2*Wo+8) x 3 input patch is read ONCE from the
+// NCHW fp32 image (coalesced along W), converted to bf16 and kept in LDS; the whole 64 x 192 weight matrix sits in
+// LDS too and each wave keeps its 24 B-fragments in registers for all of its M tiles.  The implicit-GEMM K index is
+// (c, r, s8) with s padded 7 -> 8, so the 8 contraction values of one MFMA operand are 8 CONSECUTIVE input pixels of
+// one (channel, row): 4 aligned ds_read_b32 straight out of the patch, no im2col in memory.
+//   out  : NHWC bf16 [B][Ho][Wo][64]   (raw conv output; BN+ReLU+MaxPool is fused in vqa_stem_pool_fwd)
+//   stats: per-workgroup column sums / sums of squares [gridDim][2][64] for train-mode BatchNorm
+#include "common.h"
+
+namespace {
+constexpr int RB = 4;          // output rows per workgroup
+constexpr int PR = 2 * RB + 5; // patch rows
+constexpr int KP = 192;        // padded K = 24 (c,r) pairs x 8
+constexpr int LDW = KP + 8;    // weight row stride in LDS (elements)
+constexpr int LDCS = 64 + 8;   // C staging row stride
+}
+
+// wstem[n][(c*7+r)*8+s] = w[n][r][s][c] (KRSC fp32 master), zero for s == 7 and pairs 21..23
+__global__ void stem_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * KP) return;
+  const int n = i / KP, k = i - n * KP, pair = k >> 3, s = k & 7;
+  float v = 0.f;
+  if (pair < 21 && s < 7) { const int c = pair / 7, r = pair - c * 7; v = w[((n * 7 + r) * 7 + s) * 3 + c]; }
+  out[i] = f2bf(v);
+}
+
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wst, bf16_t* __restrict__ out,
+                                                        float* __restrict__ stats, int H, int W, int Ho, int Wo) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int PW = 2 * Wo + 8;                       // patch width (x = iw + 3), multiple of 8
+  bf16_t* patch = reinterpret_cast<bf16_t*>(smem);                 // [3][PR][PW]
+  bf16_t* Wl = patch + 3 * PR * PW;                                 // [64][LDW]
+  bf16_t* Cst = Wl;                                                 // [4 waves][16][LDCS], aliases Wl once the B fragments are in registers
+  float* red = reinterpret_cast<float*>(Wl + 64 * LDW);             // [4][64][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int rblocks = Ho / RB;
+  const int b = blockIdx.x / rblocks, oh0 = (blockIdx.x - b * rblocks) * RB;
+
+  // ---- stage weights (16-byte vectors) and the input patch (fp32 -> bf16)
+  for (int v = tid; v < 64 * (KP / 8); v += 256) {
+    const int n = v / (KP / 8), kv = v - n * (KP / 8);
+    *reinterpret_cast<u32x4*>(&Wl[n * LDW + kv * 8]) = *reinterpret_cast<const u32x4*>(&wst[n * KP + kv * 8]);
+  }
+  const int ih_base = 2 * oh0 - 3;
+  for (int i = tid; i < 3 * PR * PW; i += 256) {
+    const int x = i % PW, q = i / PW, pr = q % PR, c = q / PR;
+    const int ih = ih_base + pr, iw = x - 3;
+    float v = 0.f;
+    if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = img[((size_t)(b * 3 + c) * H + ih) * W + iw];
+    patch[i] = f2bf(v);
+  }
+  __syncthreads();
+
+  // ---- B fragments: 6 k-steps x 4 column tiles, resident in registers
+  bf16x8 bfr[6][4];
+#pragma unroll
+  for (int kk = 0; kk < 6; ++kk)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      bfr[kk][nt] = *reinterpret_cast<const bf16x8*>(&Wl[(nt * 16 + li) * LDW + kk * 32 + g * 8]);
+  __syncthreads();                                    // every wave has its B fragments: Wl may now be reused as C staging
+
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  const int mtiles_row = Wo / 16, mtiles = RB * mtiles_row;
+  bf16_t* mycs = Cst + wave * 16 * LDCS;
+  for (int mt = wave; mt < mtiles; mt += 4) {
+    const int orow = mt / mtiles_row, ow0 = (mt - orow * mtiles_row) * 16;
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) {
+      int pair = kk * 4 + g;
+      pair = pair > 20 ? 20 : pair;                     // pairs 21..23 have zero weights; read any valid patch row
+      const int c = pair / 7, r = pair - c * 7;
+      const uint32_t* ap = reinterpret_cast<const uint32_t*>(&patch[(c * PR + 2 * orow + r) * PW + 2 * (ow0 + li)]);
+      u32x4 raw = {ap[0], ap[1], ap[2], ap[3]};
+      const bf16x8 af = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[kk][nt], acc[nt], 0, 0, 0);
+    }
+    // epilogue: BN partial sums from the fp32 accumulators, bf16 tile through LDS, 16-byte row stores
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[nt][r];
+        ssum[nt] += v; ssq[nt] += v * v;
+        mycs[(g * 4 + r) * LDCS + nt * 16 + li] = f2bf(v);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private staging buffer: writes done, and a compiler fence
+    const size_t obase = (((size_t)b * Ho + oh0 + orow) * Wo + ow0) * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = lane + 64 * i, px = v >> 3, cv = v & 7;
+      *reinterpret_cast<u32x4*>(&out[obase + (size_t)px * 64 + cv * 8]) = *reinterpret_cast<const u32x4*>(&mycs[px * LDCS + cv * 8]);
+    }
+    asm volatile("" ::: "memory");
+  }
+  if (stats) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float s = ssum[nt], q = ssq[nt];
+      s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+      if (lane < 16) { red[(wave * 64 + nt * 16 + lane) * 2] = s; red[(wave * 64 + nt * 16 + lane) * 2 + 1] = q; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
+      stats[((size_t)blockIdx.x * 2) * 64 + tid] = s;
+      stats[((size_t)blockIdx.x * 2 + 1) * 64 + tid] = q;
+    }
+  }
+}
+
+extern "C" {
+
+// number of workgroups (= rows of the statistics slab) or 0 when the shape is not supported by this kernel
+int vqa_stem_conv_blocks(int B, int H, int W) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  if (Ho % RB || Wo % 16 || Wo > 256) return 0;
+  return B * (Ho / RB);
+}
+int vqa_stem_pack(const float* w_krsc, void* wstem /* [64][192] bf16 */, hipStream_t st) {
+  if (!w_krsc || !wstem) return VQA_EARG;
+  hipLaunchKernelGGL(stem_pack_kernel, dim3((64 * KP + 255) / 256), dim3(256), 0, st, w_krsc, (bf16_t*)wstem);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+// bf16 only.  img NCHW fp32 [B][3][H][W]; out NHWC bf16 [B][Ho][Wo][64]; stats [vqa_stem_conv_blocks][2][64] or NULL
+int vqa_stem_conv(const float* img, const void* wstem, void* out, float* stats, int B, int H, int W, hipStream_t st) {
+  const int nb = vqa_stem_conv_blocks(B, H, W);
+  if (!img || !wstem || !out || nb <= 0) return VQA_EARG;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1, PW = 2 * Wo + 8;
+  const size_t shm = (size_t)(3 * PR * PW + 64 * LDW) * 2 + 4 * 64 * 2 * 4;
+  static size_t attr = 0;
+  if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(nb), dim3(256), shm, st, img, (const bf16_t*)wstem, (bf16_t*)out, stats, H, W, Ho, Wo);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+
+}  // extern "C"

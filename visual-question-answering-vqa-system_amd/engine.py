@@ -66,6 +66,10 @@ class HipEngine:
         kp = (147 + bk - 1) // bk * bk
         self.stem_kp = kp
         self.stem_w = K.pack_rows(LY.mat_of(self.flat, self.E["image_encoder.stem.0.weight"]), self.dtype, kp)
+        self.stem_w2 = None
+        if self.dtype == torch.bfloat16:            # operand of the dedicated bf16 stem kernel: [64][(c,r,s8)]
+            self.stem_w2 = torch.empty((64, 192), device=self.flat.device, dtype=torch.bfloat16)
+            call("vqa_stem_pack", ptr(self.P("image_encoder.stem.0.weight")), ptr(self.stem_w2))
 
     def _seed(self):
         self._site += 1
@@ -172,7 +176,10 @@ class HipEngine:
         H1, W1 = (IH + 6 - 7) // 2 + 1, (IW + 6 - 7) // 2 + 1
         M = B * H1 * W1
         sgeom = (B, IH, IW, 3, H1, W1, 7, 7, 2, 3)
-        y, st, mt = K.igemm(images, self.stem_w, M, 64, self.stem_kp, sgeom, dtype=T, loader=K.LOADER_STEM, want_stats=training)
+        if self.stem_w2 is not None and K.stem_conv_blocks(B, IH, IW) > 0:
+            y, st, mt = K.stem_conv(images, self.stem_w2, B, IH, IW, training)
+        else:
+            y, st, mt = K.igemm(images, self.stem_w, M, 64, self.stem_kp, sgeom, dtype=T, loader=K.LOADER_STEM, want_stats=training)
         coef = self._bn_coef("image_encoder.stem.1", st, mt, 64, M, training)
         Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         x = torch.empty((B * Hp * Wp, 64), device=dev, dtype=T)
@@ -494,9 +501,20 @@ class HipEngine:
         if has_ds:
             gd = rec["gd"]
             K.wgrad(dyd, rec["x"], LY.mat_of(G, self.E[p + ".downsample.0.weight"]), M, Cout, Cin, gd, dtype=T)
-            geom_dd = (B, Ho, Wo, Cout, H, W, 1, 1, stride, 0)
-            dxd, _, _ = K.igemm(dyd, self.Wt(p + ".downsample.0.weight"), Md, Cin, Cout, geom_dd, dtype=T, transposed=1)
-            dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1, addend=dxd)
+            if stride == 2 and H % 2 == 0 and W % 2 == 0:
+                # conv1 (3x3/2) and shortcut (1x1/2) data gradients in ONE launch over parity classes: no redundant taps
+                wt = self._wt.get(p + ".dgrad2")
+                if wt is None:
+                    wt = torch.empty((Cin, 10 * Cout), device=dout.device, dtype=T)
+                    K.pack_transpose(LY.mat_of(self.flat, self.E[p + ".conv1.weight"]).view(Cout, 9, Cin), T, out=wt, ldo=10 * Cout, col0=0)
+                    K.pack_transpose(LY.mat_of(self.flat, self.E[p + ".downsample.0.weight"]).view(Cout, 1, Cin), T, out=wt, ldo=10 * Cout,
+                                     col0=9 * Cout)
+                    self._wt[p + ".dgrad2"] = wt
+                dx = K.dgrad_s2(dy1, dyd, wt, B, Ho, Wo, Cout, H, W, Cin, 3, 1, dtype=T)
+            else:
+                geom_dd = (B, Ho, Wo, Cout, H, W, 1, 1, stride, 0)
+                dxd, _, _ = K.igemm(dyd, self.Wt(p + ".downsample.0.weight"), Md, Cin, Cout, geom_dd, dtype=T, transposed=1)
+                dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1, addend=dxd)
         else:
             dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
                                addend=dout, addmask=rec["out"])

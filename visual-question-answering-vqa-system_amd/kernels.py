@@ -47,12 +47,48 @@ def pack_rows(w2d: torch.Tensor, dtype, kp=None) -> torch.Tensor:
     return out
 
 
-def pack_transpose(w3d: torch.Tensor, dtype) -> torch.Tensor:
-    """[N][T][C] fp32 -> [C][T][N] T (the data-gradient operand)."""
+def pack_transpose(w3d: torch.Tensor, dtype, out=None, ldo=None, col0=0) -> torch.Tensor:
+    """[N][T][C] fp32 -> out[c][col0 + t*N + n] T (the data-gradient operand; row stride ldo)."""
     n, t, c = w3d.shape
-    out = torch.empty((c, t, n), device=w3d.device, dtype=dtype)
-    call("vqa_pack_transpose", dt(dtype), ptr(w3d), ptr(out), n, t, c)
+    if out is None:
+        out = torch.empty((c, t, n), device=w3d.device, dtype=dtype)
+        ldo = t * n
+    call("vqa_pack_transpose", dt(dtype), ptr(w3d), ptr(out), n, t, c, ldo, col0)
     return out
+
+
+def dgrad_s2(dy, dyd, wt, B, H, W, C, Ho, Wo, N, R, pad, *, dtype):
+    """Data gradient of a stride-2 conv (+ optional 1x1/2 shortcut) with rows grouped by parity class."""
+    out = torch.empty((B * Ho * Wo, N), device=dy.device, dtype=dtype)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_dgrad_s2", dt(dtype), ptr(dy), ptr(dyd), ptr(wt), ptr(out), B, H, W, C, Ho, Wo, N, R, pad)
+    if PROFILE is not None:
+        e1.record()
+        flops = 2.0 * B * H * W * C * N * (R * R + (1 if dyd is not None else 0))
+        PROFILE.append((f"igemm_kernel<{_tname(dtype)}, 128, {64 if N <= 64 else 128}, 2>", flops, e0, e1))
+    return out
+
+
+def stem_conv_blocks(B, H, W) -> int:
+    return L.count("vqa_stem_conv_blocks", B, H, W)
+
+
+def stem_conv(img, wstem, B, H, W, want_stats):
+    """bf16 stem conv 7x7/2 from the NCHW fp32 image.  Returns (y [B*Ho*Wo, 64] bf16, stats slab | None, blocks)."""
+    nb = stem_conv_blocks(B, H, W)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    y = torch.empty((B * Ho * Wo, 64), device=img.device, dtype=torch.bfloat16)
+    stats = torch.empty((nb, 2, 64), device=img.device, dtype=torch.float32) if want_stats else None
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_stem_conv", ptr(img), ptr(wstem), ptr(y), ptr(stats), B, H, W)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("stem_conv_kernel", 2.0 * B * Ho * Wo * 64 * 147, e0, e1))
+    return y, stats, nb
 
 
 def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=None, addmask=None, want_stats=False,
