@@ -186,3 +186,20 @@ def test_stem_conv_bf16_dedicated_kernel(hw):
     assert _relerr(y.float().cpu(), y_ref) < 1.2e-2
     s = stats.sum(0).cpu()
     assert _relerr(s[0], y_ref.sum(0)) < 5e-3 and _relerr(s[1], (y_ref ** 2).sum(0)) < 5e-3
+
+
+@pytest.mark.parametrize("hw", [(224, 224), (64, 64), (96, 160)])
+def test_stem_wgrad_bf16_dedicated_kernel(hw):
+    K = sub("kernels")
+    H, W = hw
+    B = 3
+    g = torch.Generator().manual_seed(W)
+    img = torch.randn(B, 3, H, W, generator=g)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = _round(torch.randn(B, 64, Ho, Wo, generator=g), torch.bfloat16)
+    w = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    F.conv2d(_round(img, torch.bfloat16), w, None, stride=2, padding=3).backward(dy)
+    dw = torch.zeros(64, 147, device=DEV)
+    K.stem_wgrad(img.to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16), dw, B, H, W)
+    torch.cuda.synchronize()
+    assert _relerr(dw.cpu(), w.grad.permute(0, 2, 3, 1).reshape(64, 147)) < 3e-3

@@ -138,18 +138,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 
 // reduce slab over blocks; emit dgamma/dbeta (+=) and the apply coefficients  dy = A*g + Bc*y + Cc
 // bcoef layout (3*C): A | Bc | Cc
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nblk, int C, int which, double count,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nblk, int C, int which, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ coef, int training,
                                        float* dgamma, float* dbeta, float* __restrict__ bcoef) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), tl = threadIdx.x >> 6;
-  __shared__ double sh[2][4][64];
+  __shared__ double sh[2][16][64];
   double sg = 0.0, sx = 0.0;
   if (c < C)
-    for (int b = tl; b < nblk; b += 4) { sg += slab[((size_t)b * 3) * C + c]; sx += slab[((size_t)b * 3 + which) * C + c]; }
+    for (int b = tl; b < nblk; b += 16) { sg += slab[((size_t)b * 3) * C + c]; sx += slab[((size_t)b * 3 + which) * C + c]; }
   sh[0][tl][threadIdx.x & 63] = sg; sh[1][tl][threadIdx.x & 63] = sx;
   __syncthreads();
   if (tl != 0 || c >= C) return;
-  for (int i = 1; i < 4; ++i) { sg += sh[0][i][threadIdx.x]; sx += sh[1][i][threadIdx.x]; }
+  for (int i = 1; i < 16; ++i) { sg += sh[0][i][threadIdx.x]; sx += sh[1][i][threadIdx.x]; }
   if (dgamma) dgamma[c] += (float)sx;
   if (dbeta) dbeta[c] += (float)sg;
   const float mean = coef[2 * C + c], invstd = coef[3 * C + c], gi = gamma[c] * invstd;
@@ -614,7 +614,7 @@ int vqa_bn_apply(int dtype, const void* y, const float* coef, const void* res, c
      hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)y, coef, (const bf16_t*)res, rcoef, (bf16_t*)out, rows, C, relu));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
-int vqa_bn_bwd_blocks(long long rows) { long long g = (rows + 63) / 64; return (int)(g > 1024 ? 1024 : (g < 1 ? 1 : g)); }
+int vqa_bn_bwd_blocks(long long rows) { long long g = (rows + 63) / 64; return (int)(g > 768 ? 768 : (g < 1 ? 1 : g)); }
 // slab: [vqa_bn_bwd_blocks(rows)][3][C] floats
 int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const void* y, const float* coef, const void* y2, const float* coef2,
                       float* slab, long long rows, int C, hipStream_t st) {
@@ -628,7 +628,7 @@ int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const voi
 }
 int vqa_bn_bwd_finalize(const float* slab, int nblk, int C, int which, double count, const float* gamma, const float* coef, int training,
                         float* dgamma, float* dbeta, float* bcoef, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, nblk, C, which, count, gamma, coef, training, dgamma, dbeta, bcoef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, slab, nblk, C, which, count, gamma, coef, training, dgamma, dbeta, bcoef);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_bn_bwd_apply(int dtype, const void* dout, const void* outact, const void* y, const float* bc, void* dy,

@@ -29,8 +29,8 @@ struct IGemmParams {
 };
 
 template <typename T> struct GT;
-template <> struct GT<float>  { static constexpr int VEC = 4, BK = 32, MK = 4; };
-template <> struct GT<bf16_t> { static constexpr int VEC = 8, BK = 64, MK = 32; };
+template <> struct GT<float>  { static constexpr int VEC = 4, BK = 32, MK = 4, BKM = 32; };
+template <> struct GT<bf16_t> { static constexpr int VEC = 8, BK = 64, MK = 32, BKM = 64; };
 
 struct RowInfo { int pix, ih0, iw0; };
 
@@ -336,7 +336,7 @@ struct WgradParams {
 template <typename T, int BMW, int BNW, int LOADER>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   using G = GT<T>;
-  constexpr int VEC = G::VEC, BKM = 32;
+  constexpr int VEC = G::VEC, BKM = G::BKM;
   constexpr int LDY = BMW + VEC, LDX = BNW + VEC;
   constexpr int TMW = BMW / 2, TNW = BNW / 2, MT = TMW / 16, NT = TNW / 16;
   constexpr int VRY = BMW / VEC, VRX = BNW / VEC;
@@ -402,30 +402,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       // ds_read_b64_tr_b16: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block and
       // receives column (lane&15) of the four rows -> two reads give the 8 contraction values of one MFMA operand.
       const int q = li >> 2, pp = li & 3;
-      const T* yb = Ys + (buf * BKM + 8 * g + q) * LDY + wm * TMW + 4 * pp;
-      const T* xb = Xs + (buf * BKM + 8 * g + q) * LDX + wn * TNW + 4 * pp;
-      bf16x8 af[MT], bfv[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + i * 16));
-        i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + 4 * LDY + i * 16));
+      for (int ks = 0; ks < BKM / 32; ++ks) {
+        const T* yb = Ys + (buf * BKM + ks * 32 + 8 * g + q) * LDY + wm * TMW + 4 * pp;
+        const T* xb = Xs + (buf * BKM + ks * 32 + 8 * g + q) * LDX + wn * TNW + 4 * pp;
         typedef __attribute__((ext_vector_type(8))) short i16x8;
-        i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        af[i] = __builtin_bit_cast(bf16x8, t);
+        bf16x8 af[MT], bfv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + i * 16));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + 4 * LDY + i * 16));
+          i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          af[i] = __builtin_bit_cast(bf16x8, t);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + j * 16));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + 4 * LDX + j * 16));
+          i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bfv[j] = __builtin_bit_cast(bf16x8, t);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + j * 16));
-        i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + 4 * LDX + j * 16));
-        typedef __attribute__((ext_vector_type(8))) short i16x8;
-        i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bfv[j] = __builtin_bit_cast(bf16x8, t);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
       for (int kk = 0; kk < BKM / 4; ++kk) {
@@ -520,7 +522,7 @@ static int igemm_dispatch(const IGemmParams& p, int loader, hipStream_t st) {
 template <typename T, int BMW, int BNW, int LOADER>
 static int launch_wgrad(const WgradParams& p, int nsplit, hipStream_t st) {
   constexpr int VEC = GT<T>::VEC;
-  constexpr int SMEM = 2 * 32 * (BMW + VEC + BNW + VEC) * (int)sizeof(T);
+  constexpr int SMEM = 2 * GT<T>::BKM * (BMW + VEC + BNW + VEC) * (int)sizeof(T);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BMW, BNW, LOADER>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -630,7 +632,7 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
   int chunk = (int)((M + nsplit - 1) / nsplit);
-  chunk = (chunk + 31) / 32 * 32;
+  chunk = (chunk + 63) / 64 * 64;
   nsplit = (M + chunk - 1) / chunk;
   p.chunk = chunk;
   if (loader == LOADER_STEM)

@@ -119,6 +119,114 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Stem weight gradient: dW[n][(r,s,c)] += sum_pixels dy[pixel][n] * im2col(img)[pixel][(c,r,s8)]
+// Persistent workgroups walk (image, 2-output-row) blocks; per output row the im2col slice [pixels][192] is built in LDS
+// from the resident patch, dy's row is staged [pixels][64], and both MFMA operands are read with ds_read_b64_tr_b16
+// (contraction index = pixel).  Partial dW stays in registers over the whole walk; one atomic flush per workgroup.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int RBW = 2;             // output rows per block
+constexpr int PRW = 2 * RBW + 5;   // patch rows
+constexpr int LDA = KP + 8;        // im2col row stride
+constexpr int LDD = 64 + 4;        // dy row stride
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy, float* __restrict__ dw,
+                                                         int B, int H, int W, int Ho, int Wo) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int PW = 2 * Wo + 8;
+  const int MP = (Wo + 31) / 32 * 32;                                // pixels per row padded to the MFMA K step
+  bf16_t* patch = reinterpret_cast<bf16_t*>(smem);                   // [3][PRW][PW]
+  bf16_t* Acol = patch + 3 * PRW * PW;                               // [MP][LDA]
+  bf16_t* Dy = Acol + MP * LDA;                                      // [MP][LDD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int q = li >> 2, pp = li & 3;
+  // zero the padded pixel rows once (they are never written again)
+  for (int i = tid; i < (MP - Wo) * LDA; i += 256) Acol[Wo * LDA + i] = 0;
+  for (int i = tid; i < (MP - Wo) * LDD; i += 256) Dy[Wo * LDD + i] = 0;
+
+  f32x4 acc[4][3];                                                   // wave owns k2 tiles 3*wave .. 3*wave+2, all 4 n tiles
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int rblocks = Ho / RBW, nblocks = B * rblocks;
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBW;
+    __syncthreads();                                                 // previous block's readers are done with the patch
+    const int ih_base = 2 * oh0 - 3;
+    for (int i = tid; i < 3 * PRW * PW; i += 256) {
+      const int x = i % PW, qq = i / PW, pr = qq % PRW, c = qq / PRW;
+      const int ih = ih_base + pr, iw = x - 3;
+      float v = 0.f;
+      if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = img[((size_t)(b * 3 + c) * H + ih) * W + iw];
+      patch[i] = f2bf(v);
+    }
+    for (int orow = 0; orow < RBW; ++orow) {
+      __syncthreads();                                               // patch ready / previous row's MFMA reads done
+      // dy row -> LDS (16-byte vectors), im2col slice -> LDS
+      const bf16_t* dyr = dy + (((size_t)b * Ho + oh0 + orow) * Wo) * 64;
+      for (int v = tid; v < Wo * 8; v += 256) {
+        const int px = v >> 3, cv = v & 7;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(dyr + (size_t)px * 64 + cv * 8);
+        uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[px * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned
+        d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
+      }
+      for (int v = tid; v < Wo * 24; v += 256) {
+        const int px = v / 24, pair = v - px * 24;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (pair < 21) {
+          const int c = pair / 7, r = pair - c * 7;
+          const uint32_t* ap = reinterpret_cast<const uint32_t*>(&patch[(c * PRW + 2 * orow + r) * PW + 2 * px]);
+          val = u32x4{ap[0], ap[1], ap[2], ap[3] & 0x0000ffffu};     // s8 = 7 is padding
+        }
+        *reinterpret_cast<u32x4*>(&Acol[px * LDA + pair * 8]) = val;
+      }
+      __syncthreads();
+      typedef __attribute__((ext_vector_type(8))) short i16x8;
+      for (int ks = 0; ks < MP / 32; ++ks) {
+        const bf16_t* yb = Dy + (ks * 32 + 8 * g + q) * LDD + 4 * pp;
+        const bf16_t* xb = Acol + (ks * 32 + 8 * g + q) * LDA + wave * 48 + 4 * pp;
+        bf16x8 af[4], bfv[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + i * 16));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + 4 * LDD + i * 16));
+          i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          af[i] = __builtin_bit_cast(bf16x8, t);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + j * 16));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + 4 * LDA + j * 16));
+          i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bfv[j] = __builtin_bit_cast(bf16x8, t);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // flush: D[i = n][j = k2], k2 = (c*7+r)*8+s  ->  dw[n][(r*7+s)*3+c]
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int k2 = wave * 48 + j * 16 + li, pair = k2 >> 3, s = k2 & 7;
+    if (pair >= 21 || s >= 7) continue;
+    const int c = pair / 7, r = pair - c * 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        atomicAdd(dw + (size_t)(i * 16 + g * 4 + rr) * 147 + (r * 7 + s) * 3 + c, acc[i][j][rr]);
+  }
+}
+
 extern "C" {
 
 // number of workgroups (= rows of the statistics slab) or 0 when the shape is not supported by this kernel
@@ -141,6 +249,21 @@ int vqa_stem_conv(const float* img, const void* wstem, void* out, float* stats, 
   static size_t attr = 0;
   if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
   hipLaunchKernelGGL(stem_conv_kernel, dim3(nb), dim3(256), shm, st, img, (const bf16_t*)wstem, (bf16_t*)out, stats, H, W, Ho, Wo);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+
+// bf16 only.  dw [64][7][7][3] fp32 (+=).  Same shape support as vqa_stem_conv.
+int vqa_stem_wgrad(const float* img, const void* dy, float* dw, int B, int H, int W, hipStream_t st) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  if (!img || !dy || !dw || Ho % RBW || Wo % 16 || Wo > 256) return VQA_EARG;
+  const int PW = 2 * Wo + 8, MP = (Wo + 31) / 32 * 32;
+  const size_t shm = (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
+  if (shm > 160 * 1024) return VQA_EARG;
+  static size_t attr = 0;
+  if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
+  int nblocks = B * (Ho / RBW);
+  int grid = nblocks < 512 ? nblocks : 512;
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)dy, dw, B, H, W, Ho, Wo);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 

@@ -406,7 +406,7 @@ int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
 int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* gamma, const float* stats, const void* addend, void* dx,
                       float* dgamma, float* dbeta, int rows, int D, float p, unsigned long long seed, float* dadd, int period, hipStream_t st) {
   if (D > 512 || rows <= 0) return VQA_EARG;
-  const int grid = (rows + 63) / 64 > 1024 ? 1024 : (rows + 63) / 64;
+  const int grid = (rows + 15) / 16 > 2048 ? 2048 : (rows + 15) / 16;
   DT(hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)x, gamma, stats, (const float*)addend, (float*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period),
      hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, stats, (const bf16_t*)addend, (bf16_t*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period));
   VQA_LAUNCH_CHECK(); return VQA_OK;

@@ -472,8 +472,11 @@ class HipEngine:
              int(training), ptr(self._gslice(G, bnp + ".weight")), ptr(self._gslice(G, bnp + ".bias")), ptr(bc))
         dy = torch.empty_like(st["y"])
         call("vqa_stem_bwd_apply", dt(T), ptr(dxc), ptr(st["idx"]), ptr(st["y"]), ptr(st["coef"]), ptr(bc), ptr(dy), B, H1, W1, 64)
-        K.wgrad(dy, st["images"], LY.mat_of(G, self.E["image_encoder.stem.0.weight"]), B * H1 * W1, 64, 147, st["geom"], dtype=T,
-                loader=K.LOADER_STEM)
+        if self.stem_w2 is not None and K.stem_conv_blocks(B, IH, IW) > 0:
+            K.stem_wgrad(st["images"], dy, self._gslice(G, "image_encoder.stem.0.weight"), B, IH, IW)
+        else:
+            K.wgrad(dy, st["images"], LY.mat_of(G, self.E["image_encoder.stem.0.weight"]), B * H1 * W1, 64, 147, st["geom"], dtype=T,
+                    loader=K.LOADER_STEM)
         seg("image_encoder.stem")
 
     def _block_bwd(self, rec, dout, G, training):

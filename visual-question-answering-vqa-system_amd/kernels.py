@@ -71,6 +71,18 @@ def dgrad_s2(dy, dyd, wt, B, H, W, C, Ho, Wo, N, R, pad, *, dtype):
     return out
 
 
+def stem_wgrad(img, dy, dw, B, H, W):
+    """bf16 stem weight gradient: dw [64][7][7][3] fp32 += dy^T im2col(img)."""
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_stem_wgrad", ptr(img), ptr(dy), ptr(dw), B, H, W)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("stem_wgrad_kernel", 2.0 * B * Ho * Wo * 64 * 147, e0, e1))
+
+
 def stem_conv_blocks(B, H, W) -> int:
     return L.count("vqa_stem_conv_blocks", B, H, W)
 
