@@ -25,6 +25,7 @@ struct IGemmParams {
   float drop_p; unsigned long long drop_seed;   // dropout applied after bias/relu, before the addend
   // LOADER_DGRAD2 (data gradient of a stride-2 conv, rows grouped by output parity class so only valid taps are issued):
   const void* a2;                               // second source (dY of the 1x1 shortcut), same geometry as a
+  unsigned a_bytes, a2_bytes, w_bytes;          // buffer extents for the hardware range check
   int ntaps[4]; int tap_koff[4][5]; int tap_dh[4][5]; int tap_dw[4][5]; int tap_src[4][5];
 };
 
@@ -136,39 +137,73 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   Vec16<T> ra[AV], rb[BV];
-  const int cpb = p.C / BK;                       // K steps per tap (DGRAD2)
-  const int nk = (LOADER == LOADER_DGRAD2) ? p.ntaps[cls] * cpb : p.Kp / BK;
   const int taps = p.R * p.S;
+  // K steps per tap; a Linear (1 tap) keeps all its K steps in "tap 0"
+  const int cpb = (LOADER == LOADER_DGRAD2 || taps > 1) ? p.C / BK : p.Kp / BK;
+  const int nk = (LOADER == LOADER_DGRAD2) ? p.ntaps[cls] * cpb : p.Kp / BK;
+
+  // ---- operand loads: buffer loads with 32-bit byte offsets; out-of-range offsets return zeros in hardware,
+  //      so padding / tile tails cost no selects.  Per-row offsets are recomputed only when the filter tap changes.
+  constexpr int OOB = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a2 ? p.a2 : p.a), 0, (int)p.a2_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  int aoff[AV], boff[BV];
+#pragma unroll
+  for (int i = 0; i < BV; ++i) {
+    const int n = n0 + rbase + 32 * i;
+    boff[i] = (n < p.N) ? (n * p.Kw + vec * VEC) * (int)sizeof(T) : OOB;
+  }
+  auto set_tap = [&](int r, int s) {          // r,s: filter tap (NHWC) or (dh,dw) source offsets (DGRAD2)
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      bool ok = ri[i].pix >= 0;
+      int ih, iw;
+      if (LOADER == LOADER_DGRAD2 || !p.transposed) { ih = ri[i].ih0 + r; iw = ri[i].iw0 + s; }
+      else {
+        const int th = ri[i].ih0 - r, tw = ri[i].iw0 - s;
+        ok = ok && th >= 0 && tw >= 0;
+        if (p.stride == 1) { ih = th; iw = tw; }
+        else { ih = th / p.stride; iw = tw / p.stride; ok = ok && (ih * p.stride == th) && (iw * p.stride == tw); }
+      }
+      ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      aoff[i] = ok ? ((ri[i].pix + ih * p.W + iw) * p.C + vec * VEC) * (int)sizeof(T) : OOB;
+    }
+  };
+  int cc = 0, tap = 0, tr_ = 0, ts_ = 0;
+  if (LOADER == LOADER_DGRAD2) { if (nk > 0) set_tap(p.tap_dh[cls][0], p.tap_dw[cls][0]); }
+  else if (LOADER == LOADER_NHWC) set_tap(0, 0);
 
   auto gload = [&](int kt) {
-    int k0 = kt * BK;
-    if (LOADER == LOADER_DGRAD2) {
-      const int t = kt / cpb, c0 = (kt - t * cpb) * BK + vec * VEC;
-      const int dh = p.tap_dh[cls][t], dw = p.tap_dw[cls][t];
-      const T* src = p.tap_src[cls][t] ? a2T : aT;
-      k0 = p.tap_koff[cls][t] + (kt - t * cpb) * BK;
+    if (LOADER == LOADER_STEM) {
+      const int k0 = kt * BK;
 #pragma unroll
-      for (int i = 0; i < AV; ++i) {
-        const int ih = ri[i].ih0 + dh, iw = ri[i].iw0 + dw;
-        const bool ok = ri[i].pix >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-        ra[i] = ok ? ldg16(src + ((size_t)(ri[i].pix + ih * p.W + iw)) * p.C + c0) : zero16<T>();
+      for (int i = 0; i < AV; ++i) ra[i] = load_a_stem<T>(aImg, ri[i], k0 + vec * VEC, p.H, p.W, 147);
+#pragma unroll
+      for (int i = 0; i < BV; ++i) {
+        const int n = n0 + rbase + 32 * i, k = k0 + vec * VEC;
+        rb[i] = (n < p.N && k < p.Kw) ? ldg16(wT + (size_t)n * p.Kw + k) : zero16<T>();
       }
-    } else if (LOADER == LOADER_NHWC) {
-      int tap = 0, c0 = k0;
-      if (taps > 1) { tap = k0 / p.C; c0 = k0 - tap * p.C; }
-      const int r = tap / p.S, s = tap - r * p.S;
-#pragma unroll
-      for (int i = 0; i < AV; ++i)
-        ra[i] = load_a_nhwc<T>(aT, ri[i], r, s, c0 + vec * VEC, p.H, p.W, p.C, p.stride, p.transposed);
-    } else {
-#pragma unroll
-      for (int i = 0; i < AV; ++i)
-        ra[i] = load_a_stem<T>(aImg, ri[i], k0 + vec * VEC, p.H, p.W, 147);
+      return;
     }
+    const int kbyte = cc * BK * (int)sizeof(T);
+    const bool cok = (taps > 1 || LOADER == LOADER_DGRAD2) ? true : (cc * BK + vec * VEC) < p.C;      // Linear K tail
+    const bool second = (LOADER == LOADER_DGRAD2) && p.tap_src[cls][tap];
 #pragma unroll
-    for (int i = 0; i < BV; ++i) {
-      const int n = n0 + rbase + 32 * i, k = k0 + vec * VEC;
-      rb[i] = (n < p.N && k < p.Kw) ? ldg16(wT + (size_t)n * p.Kw + k) : zero16<T>();
+    for (int i = 0; i < AV; ++i) {
+      const int vo = cok ? aoff[i] + kbyte : OOB;
+      ra[i].raw = second ? __builtin_amdgcn_raw_buffer_load_b128(rsA2, vo, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0);
+    }
+    const int kw = (LOADER == LOADER_DGRAD2) ? p.tap_koff[cls][tap] + cc * BK : kt * BK;
+    const bool kok = (kw + vec * VEC) < p.Kw;
+#pragma unroll
+    for (int i = 0; i < BV; ++i)
+      rb[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsW, kok ? boff[i] + kw * (int)sizeof(T) : OOB, 0, 0);
+    // advance the (tap, channel-chunk) cursor for the next call
+    if (++cc == cpb) {
+      cc = 0; ++tap;
+      if (LOADER == LOADER_DGRAD2) { if (tap < p.ntaps[cls]) set_tap(p.tap_dh[cls][tap], p.tap_dw[cls][tap]); }
+      else { if (++ts_ == p.S) { ts_ = 0; ++tr_; } if (tr_ < p.R) set_tap(tr_, ts_); }
     }
   };
   auto sstore = [&](int buf) {
@@ -331,6 +366,8 @@ struct WgradParams {
   const void* dy; const void* x; float* dw;
   int M, N, Kw;              // dy [M][N]; dw [N][Kw] fp32 (+=)
   int B, H, W, C, Ho, Wo, R, S, stride, pad, chunk;
+  unsigned dy_bytes, x_bytes;
+  unsigned long long mul_howo, mul_wo;       // ceil(2^40 / d): exact m / d for m*d < 2^40
 };
 
 template <typename T, int BMW, int BNW, int LOADER>
@@ -368,20 +405,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   Vec16<T> ry[YV], rx[XV];
 
+  constexpr int OOB = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   auto gload = [&](int ms) {
 #pragma unroll
     for (int i = 0; i < YV; ++i) {
       const int idx = tid + 256 * i, row = idx / VRY, v = idx - row * VRY;
       const int m = ms + row, n = n0 + v * VEC;
-      ry[i] = (m < mend && n < p.N) ? ldg16(dyT + (size_t)m * p.N + n) : zero16<T>();
+      ry[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsY, (m < mend && n < p.N) ? (m * p.N + n) * (int)sizeof(T) : OOB, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int idx = tid + 256 * i, row = idx / VRX, v = idx - row * VRX;
       const int m = ms + row;
-      RowInfo ri = decode_row(m, mend, HoWo, p.Wo, HW, p.stride, p.pad, 0, LOADER == LOADER_STEM);
-      if (LOADER == LOADER_NHWC) rx[i] = load_a_nhwc<T>(xT, ri, tr, ts, c0 + v * VEC, p.H, p.W, p.C, p.stride, 0);
-      else rx[i] = load_a_stem<T>(xImg, ri, k20 + v * VEC, p.H, p.W, p.Kw);
+      if (LOADER == LOADER_NHWC) {
+        int off = OOB;
+        const int c = c0 + v * VEC;
+        if (m < mend && c < p.C) {
+          const int b = (int)(((unsigned long long)m * p.mul_howo) >> 40), rem = m - b * HoWo;
+          const int oh = (int)(((unsigned long long)rem * p.mul_wo) >> 40), ow = rem - oh * p.Wo;
+          const int ih = oh * p.stride - p.pad + tr, iw = ow * p.stride - p.pad + ts;
+          if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) off = ((b * HW + ih * p.W + iw) * p.C + c) * (int)sizeof(T);
+        }
+        rx[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
+      } else {
+        RowInfo ri = decode_row(m, mend, HoWo, p.Wo, HW, p.stride, p.pad, 0, true);
+        rx[i] = load_a_stem<T>(xImg, ri, k20 + v * VEC, p.H, p.W, p.Kw);
+      }
     }
   };
   auto sstore = [&](int buf) {
@@ -563,6 +614,12 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
   p.M = M; p.N = N; p.Kw = Kw; p.Kp = (Kw + BK - 1) / BK * BK;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
   p.transposed = transposed; p.relu = relu; p.drop_p = drop_p; p.drop_seed = drop_seed; p.a2 = nullptr;
+  {
+    const size_t es = dtype ? 2 : 4;
+    const size_t ab = (size_t)B * H * W * C * es, wb = (size_t)N * Kw * es;
+    if (loader == LOADER_NHWC && (ab >= 0x7fffffffull || wb >= 0x7fffffffull)) return VQA_EARG;
+    p.a_bytes = (unsigned)(loader == LOADER_NHWC ? ab : 0); p.a2_bytes = p.a_bytes; p.w_bytes = (unsigned)wb;
+  }
   for (int c = 0; c < 4; ++c) p.ntaps[c] = 0;
   return dtype ? igemm_dispatch<bf16_t>(p, loader, st) : igemm_dispatch<float>(p, loader, st);
 }
@@ -579,6 +636,12 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
   p.N = N; p.Kw = R * R * C + (dyd ? C : 0); p.Kp = p.Kw; p.M = B * Ho * Wo;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = R; p.stride = 2; p.pad = pad;
   p.transposed = 1; p.relu = 0; p.drop_p = 0.f; p.drop_seed = 0;
+  {
+    const size_t es = dtype ? 2 : 4;
+    const size_t ab = (size_t)B * H * W * C * es, wb = (size_t)N * p.Kw * es;
+    if (ab >= 0x7fffffffull || wb >= 0x7fffffffull) return VQA_EARG;
+    p.a_bytes = (unsigned)ab; p.a2_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+  }
   for (int ph = 0; ph < 2; ++ph)
     for (int pw = 0; pw < 2; ++pw) {
       const int cls = ph * 2 + pw; int nt = 0;
@@ -622,6 +685,16 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
   WgradParams p;
   p.dy = dy; p.x = x; p.dw = dw; p.M = M; p.N = N; p.Kw = Kw; p.B = B; p.H = H; p.W = W; p.C = C;
   p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  {
+    const size_t es = dtype ? 2 : 4;
+    const size_t yb = (size_t)M * N * es, xb = (size_t)B * H * W * C * es;
+    if (yb >= 0x7fffffffull || (loader == LOADER_NHWC && xb >= 0x7fffffffull)) return VQA_EARG;
+    if ((double)M * ((double)Ho * Wo) >= 1099511627776.0) return VQA_EARG;
+    p.dy_bytes = (unsigned)yb; p.x_bytes = (unsigned)(loader == LOADER_NHWC ? xb : 0);
+    const unsigned long long one = 1ull << 40;
+    p.mul_howo = (one + (unsigned long long)(Ho * Wo) - 1) / (unsigned long long)(Ho * Wo);
+    p.mul_wo = (one + (unsigned long long)Wo - 1) / (unsigned long long)Wo;
+  }
   // tile: 128x128 when both dims allow it and (for multi-tap convs) a tile stays inside one tap
   const bool big = (N >= 128) && (R * S > 1 ? (C % 128 == 0) : (Kw >= 128));
   const int bmw = big ? 128 : 64, bnw = big ? 128 : 64;
