@@ -35,7 +35,13 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
 int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw, int M, int N, int Kw, int B, int H, int W,
               int C, int Ho, int Wo, int R, int S, int stride, int pad, hipStream_t stream);
 int vqa_pack_rows(int dtype, const float* in, void* out, int N, int K, int Kp, hipStream_t stream);          /* cast + row pad   */
-int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int T, int C, int ldo, int col0, hipStream_t stream); /* out[c][col0+t*N+n] */
+int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int T, int C, int ldo, int col0, int flip, hipStream_t stream); /* out[c][col0+t*N+n] = in[n][flip?T-1-t:t][c] */
+/* stage-1 3x3/1 conv, 64->64 channels, bf16, LDS-resident input patch (models/cnn_backbone.py:182-187 at Cin=Cout=64):
+ * forward (w = [Cout][R][S][Cin]) and data gradient (w = flipped+transposed pack, out += addend*(addmask>0)); weight gradient. */
+int vqa_conv3x3_c64_blocks(int B, int H, int W);
+int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const void* addend, const void* addmask,
+                    int B, int H, int W, hipStream_t stream);
+int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw /* [64][576] += */, int B, int H, int W, hipStream_t stream);
 /* data gradient of a stride-2 conv (+ the block's 1x1/2 shortcut, models/cnn_backbone.py:243-247) in one launch; rows are
  * grouped by output parity class so only the valid taps are issued.  dy/dyd [B][H][W][C], out [B][Ho=2H][Wo=2W][N] */
 int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, void* out, int B, int H, int W, int C,

@@ -203,3 +203,38 @@ def test_stem_wgrad_bf16_dedicated_kernel(hw):
     K.stem_wgrad(img.to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16), dw, B, H, W)
     torch.cuda.synchronize()
     assert _relerr(dw.cpu(), w.grad.permute(0, 2, 3, 1).reshape(64, 147)) < 3e-3
+
+
+@pytest.mark.parametrize("case", [(2, 56, 56), (3, 16, 24), (1, 8, 8)])
+def test_conv3x3_c64_patch_kernels(case):
+    """stage-1 LDS-patch kernels (bf16): forward + stats, data gradient with the masked identity addend, weight gradient."""
+    K = sub("kernels")
+    B, H, W = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = _round(torch.randn(B, 64, H, W, generator=g), dtype)
+    w = _round(torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5, dtype)
+    dy = _round(torch.randn(B, 64, H, W, generator=g), dtype)
+    add = _round(torch.randn(B, 64, H, W, generator=g), dtype)
+    msk = _round(torch.randn(B, 64, H, W, generator=g), dtype)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride=1, padding=1)
+    yr.backward(dy)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    w_krsc = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    assert K.c64_blocks(B, H, W) > 0
+    y, stats, nb = K.conv3x3_c64(nhwc(x), K.pack_rows(w_krsc.view(64, 576), dtype), B, H, W, want_stats=True)
+    torch.cuda.synchronize()
+    y_ref = yr.detach().permute(0, 2, 3, 1).reshape(-1, 64)
+    assert _relerr(y.float().cpu(), y_ref) < _tol(dtype)
+    s = stats.sum(0).cpu()
+    assert _relerr(s[0], y_ref.sum(0)) < 5e-3 and _relerr(s[1], (y_ref ** 2).sum(0)) < 5e-3
+    wflip = K.pack_transpose(w_krsc.view(64, 9, 64), dtype, flip=True)
+    dx, _, _ = K.conv3x3_c64(nhwc(dy), wflip, B, H, W, addend=nhwc(add), addmask=nhwc(msk))
+    torch.cuda.synchronize()
+    dx_ref = (xr.grad + add * (msk > 0)).permute(0, 2, 3, 1).reshape(-1, 64)
+    assert _relerr(dx.float().cpu(), dx_ref) < _tol(dtype)
+    dw = torch.zeros(64, 576, device=DEV)
+    K.wgrad3x3_c64(nhwc(x), nhwc(dy), dw, B, H, W)
+    torch.cuda.synchronize()
+    assert _relerr(dw.cpu(), wr.grad.permute(0, 2, 3, 1).reshape(64, 576)) < 3e-3

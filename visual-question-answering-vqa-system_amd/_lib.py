@@ -21,7 +21,10 @@ SIGNATURES = {
     "vqa_igemm": [I, I, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, P],
     "vqa_wgrad": [I, I, P, P, P] + [I] * 13 + [P],
     "vqa_pack_rows": [I, P, P, I, I, I, P],
-    "vqa_pack_transpose": [I, P, P, I, I, I, I, I, P],
+    "vqa_pack_transpose": [I, P, P, I, I, I, I, I, I, P],
+    "vqa_conv3x3_c64_blocks": [I, I, I],
+    "vqa_conv3x3_c64": [P, P, P, P, P, P, I, I, I, P],
+    "vqa_wgrad3x3_c64": [P, P, P, I, I, I, P],
     "vqa_dgrad_s2": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "vqa_stem_conv_blocks": [I, I, I],
     "vqa_stem_pack": [P, P, P],
@@ -60,7 +63,7 @@ SIGNATURES = {
     "vqa_sumsq": [P, LL, P, P],
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P],
 }
-_NO_STATUS = {"vqa_igemm_mtiles", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks"}   # return a count, not a status
+_NO_STATUS = {"vqa_igemm_mtiles", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
 
 _lib = None
 

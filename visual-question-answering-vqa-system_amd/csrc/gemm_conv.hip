@@ -12,6 +12,7 @@
 // LDS tiles hold 128 bytes of K per row (+16 B pad): [row][k] for igemm, [k][row] for wgrad
 // (wgrad reads its operands with ds_read_b64_tr_b16 so the contraction index ends up lane-contiguous).
 #include "common.h"
+#include <stdlib.h>
 
 enum { LOADER_NHWC = 0, LOADER_STEM = 1, LOADER_DGRAD2 = 2 };
 
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 struct WgradParams {
   const void* dy; const void* x; float* dw;
   int M, N, Kw;              // dy [M][N]; dw [N][Kw] fp32 (+=)
-  int B, H, W, C, Ho, Wo, R, S, stride, pad, chunk;
+  int B, H, W, C, Ho, Wo, R, S, stride, pad, chunk, dbg_noatomic;
   unsigned dy_bytes, x_bytes;
   unsigned long long mul_howo, mul_wo;       // ceil(2^40 / d): exact m / d for m*d < 2^40
 };
@@ -408,6 +409,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int OOB = (int)0x80000000;
   const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  // Staging map: a thread owns ONE pixel row of the step tile for X (so the (b,oh,ow) decode is done once per step)
+  // and XV channel vectors of it; Y uses the plain linear map.
+  constexpr int XT = 256 / BKM;                       // threads per X row
+  static_assert(VRX % XT == 0 && VRX / XT == XV, "X staging map");
+  const int xrow = tid / XT, xv0 = tid % XT;
+  const float inv_wo = 1.0f / (float)p.Wo;
   auto gload = [&](int ms) {
 #pragma unroll
     for (int i = 0; i < YV; ++i) {
@@ -415,24 +422,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       const int m = ms + row, n = n0 + v * VEC;
       ry[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsY, (m < mend && n < p.N) ? (m * p.N + n) * (int)sizeof(T) : OOB, 0, 0);
     }
+    const int m = ms + xrow;
+    if (LOADER == LOADER_NHWC) {
+      const int b = (int)(((unsigned long long)m * p.mul_howo) >> 40), rem = m - b * HoWo;
+      const int oh = (int)(((float)rem + 0.5f) * inv_wo), ow = rem - oh * p.Wo;      // exact: rem < 2^16
+      const int ih = oh * p.stride - p.pad + tr, iw = ow * p.stride - p.pad + ts;
+      const bool ok = m < mend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const int base = ok ? ((b * HW + ih * p.W + iw) * p.C + c0) * (int)sizeof(T) : OOB;
 #pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      const int idx = tid + 256 * i, row = idx / VRX, v = idx - row * VRX;
-      const int m = ms + row;
-      if (LOADER == LOADER_NHWC) {
-        int off = OOB;
-        const int c = c0 + v * VEC;
-        if (m < mend && c < p.C) {
-          const int b = (int)(((unsigned long long)m * p.mul_howo) >> 40), rem = m - b * HoWo;
-          const int oh = (int)(((unsigned long long)rem * p.mul_wo) >> 40), ow = rem - oh * p.Wo;
-          const int ih = oh * p.stride - p.pad + tr, iw = ow * p.stride - p.pad + ts;
-          if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) off = ((b * HW + ih * p.W + iw) * p.C + c) * (int)sizeof(T);
-        }
-        rx[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
-      } else {
-        RowInfo ri = decode_row(m, mend, HoWo, p.Wo, HW, p.stride, p.pad, 0, true);
-        rx[i] = load_a_stem<T>(xImg, ri, k20 + v * VEC, p.H, p.W, p.Kw);
+      for (int i = 0; i < XV; ++i) {
+        const int c = (xv0 + XT * i) * VEC;
+        rx[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsX, (c0 + c < p.C) ? base + c * (int)sizeof(T) : OOB, 0, 0);
       }
+    } else {
+      RowInfo ri = decode_row(m, mend, HoWo, p.Wo, HW, p.stride, p.pad, 0, true);
+#pragma unroll
+      for (int i = 0; i < XV; ++i) rx[i] = load_a_stem<T>(xImg, ri, k20 + (xv0 + XT * i) * VEC, p.H, p.W, p.Kw);
     }
   };
   auto sstore = [&](int buf) {
@@ -442,10 +447,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       *reinterpret_cast<u32x4*>(&Ys[(buf * BKM + row) * LDY + v * VEC]) = ry[i].raw;
     }
 #pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      const int idx = tid + 256 * i, row = idx / VRX, v = idx - row * VRX;
-      *reinterpret_cast<u32x4*>(&Xs[(buf * BKM + row) * LDX + v * VEC]) = rx[i].raw;
-    }
+    for (int i = 0; i < XV; ++i)
+      *reinterpret_cast<u32x4*>(&Xs[(buf * BKM + xrow) * LDX + (xv0 + XT * i) * VEC]) = rx[i].raw;
   };
   auto compute = [&](int buf) {
     const int g = lane >> 4, li = lane & 15;
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wm * TMW + i * 16 + (lane >> 4) * 4 + r;
         const int k2 = k20 + wn * TNW + j * 16 + (lane & 15);
-        if (n < p.N && k2 < p.Kw) atomicAdd(p.dw + (size_t)n * p.Kw + k2, acc[i][j][r]);
+        if (n < p.N && k2 < p.Kw && !p.dbg_noatomic) atomicAdd(p.dw + (size_t)n * p.Kw + k2, acc[i][j][r]);
       }
 }
 
@@ -529,12 +532,13 @@ __global__ void pack_rows_kernel(const float* __restrict__ in, T* __restrict__ o
   out[i] = from_f<T>(k < K ? in[(size_t)n * K + k] : 0.f);
 }
 template <typename T>
-__global__ void pack_transpose_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int TT, int C, int ldo, int col0) {
-  // out[c][col0 + t*N + n] = in[n][t][c]   (row stride ldo)
+__global__ void pack_transpose_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int TT, int C, int ldo, int col0, int flip) {
+  // out[c][col0 + t*N + n] = in[n][flip ? TT-1-t : t][c]   (row stride ldo)
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)N * TT * C) return;
   int n = (int)(i % N); size_t r = i / N; int t = (int)(r % TT); int c = (int)(r / TT);
-  out[(size_t)c * ldo + col0 + t * N + n] = from_f<T>(in[((size_t)n * TT + t) * C + c]);
+  const int ts = flip ? TT - 1 - t : t;
+  out[(size_t)c * ldo + col0 + t * N + n] = from_f<T>(in[((size_t)n * TT + ts) * C + c]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -700,7 +704,9 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
   const int bmw = big ? 128 : 64, bnw = big ? 128 : 64;
   if (loader == LOADER_NHWC && R * S > 1 && (C % bnw)) return VQA_EARG;
   const long tiles = (long)((N + bmw - 1) / bmw) * ((Kw + bnw - 1) / bnw);
-  long nsplit = (2048 + tiles - 1) / tiles;                 // aim for ~2048 workgroups
+  static const long target = getenv("VQA_WGRAD_TARGET") ? atol(getenv("VQA_WGRAD_TARGET")) : 2048;
+  p.dbg_noatomic = getenv("VQA_WGRAD_NOATOMIC") ? 1 : 0;
+  long nsplit = (target + tiles - 1) / tiles;                 // aim for ~target workgroups
   long maxsplit = (M + 255) / 256;                           // at least 256 rows per split
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
@@ -726,12 +732,12 @@ int vqa_pack_rows(int dtype, const float* in, void* out, int N, int K, int Kp, h
   return VQA_OK;
 }
 // out[c][col0 + t*N + n] (T, row stride ldo >= col0 + T*N) = in[N][T][C] fp32
-int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int TT, int C, int ldo, int col0, hipStream_t st) {
+int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int TT, int C, int ldo, int col0, int flip, hipStream_t st) {
   if (!in || !out || N <= 0 || TT <= 0 || C <= 0 || ldo < col0 + TT * N) return VQA_EARG;
   size_t total = (size_t)N * TT * C;
   dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype) hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, N, TT, C, ldo, col0);
-  else hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, N, TT, C, ldo, col0);
+  if (dtype) hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, N, TT, C, ldo, col0, flip);
+  else hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, N, TT, C, ldo, col0, flip);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }

@@ -84,10 +84,25 @@ class HipEngine:
         return K.bn_eval_coef(C, self.P(prefix + ".weight"), self.P(prefix + ".bias"),
                               self.buf[prefix + ".running_mean"], self.buf[prefix + ".running_var"])
 
+    def _c64_ok(self, B, H, W, Cin, Cout, R, stride):
+        return (self.dtype == torch.bfloat16 and Cin == 64 and Cout == 64 and R == 3 and stride == 1 and K.c64_blocks(B, H, W) > 0)
+
+    def _wflip(self, name):                  # [Cin][(2-r,2-s)][Cout] operand of the stride-1 data gradient as a plain 3x3 conv
+        t = self._wt.get(name + ".flip")
+        if t is None:
+            e = self.E[name]
+            n, c = e.shape[0], e.shape[1]
+            t = K.pack_transpose(LY.mat_of(self.flat, e).view(n, 9, c), self.dtype, flip=True)
+            self._wt[name + ".flip"] = t
+        return t
+
     def _conv(self, x, B, H, W, Cin, wname, Cout, R, stride, pad, stats):
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
         M = B * Ho * Wo
         geom = (B, H, W, Cin, Ho, Wo, R, R, stride, pad)
+        if self._c64_ok(B, H, W, Cin, Cout, R, stride):
+            y, st, mt = K.conv3x3_c64(x, self.Wm(wname), B, H, W, want_stats=stats)
+            return y, st, mt, geom, Ho, Wo
         y, st, mt = K.igemm(x, self.Wm(wname), M, Cout, R * R * Cin, geom, dtype=self.dtype, want_stats=stats)
         return y, st, mt, geom, Ho, Wo
 
@@ -492,13 +507,22 @@ class HipEngine:
                             dgamma2=gs(p + ".downsample.1.weight") if has_ds else None,
                             dbeta2=gs(p + ".downsample.1.bias") if has_ds else None)
         g2 = rec["g2"]; B, Ho, Wo = g2[0], g2[1], g2[2]
-        K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T)
-        geom_d2 = (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
-        da1, _, _ = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1)
+        c64_2 = self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1)
+        if c64_2:
+            K.wgrad3x3_c64(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo)
+            da1, _, _ = K.conv3x3_c64(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
+        else:
+            K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T)
+            geom_d2 = (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
+            da1, _, _ = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1)
         dy1, _ = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["c1"], self.P(p + ".bn1.weight"), Cout, training,
                           gs(p + ".bn1.weight"), gs(p + ".bn1.bias"))
         g1 = rec["g1"]; H, W, stride = g1[1], g1[2], g1[8]
-        K.wgrad(dy1, rec["x"], LY.mat_of(G, self.E[p + ".conv1.weight"]), M, Cout, 9 * Cin, g1, dtype=T)
+        c64_1 = self._c64_ok(B, H, W, Cin, Cout, 3, stride)
+        if c64_1:
+            K.wgrad3x3_c64(rec["x"], dy1, LY.mat_of(G, self.E[p + ".conv1.weight"]), B, H, W)
+        else:
+            K.wgrad(dy1, rec["x"], LY.mat_of(G, self.E[p + ".conv1.weight"]), M, Cout, 9 * Cin, g1, dtype=T)
         Md = B * H * W
         geom_d1 = (B, Ho, Wo, Cout, H, W, 3, 3, stride, 1)
         if has_ds:
@@ -518,6 +542,8 @@ class HipEngine:
                 geom_dd = (B, Ho, Wo, Cout, H, W, 1, 1, stride, 0)
                 dxd, _, _ = K.igemm(dyd, self.Wt(p + ".downsample.0.weight"), Md, Cin, Cout, geom_dd, dtype=T, transposed=1)
                 dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1, addend=dxd)
+        elif c64_1:
+            dx, _, _ = K.conv3x3_c64(dy1, self._wflip(p + ".conv1.weight"), B, H, W, addend=dout, addmask=rec["out"])
         else:
             dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
                                addend=dout, addmask=rec["out"])

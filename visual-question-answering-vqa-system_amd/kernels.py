@@ -47,14 +47,43 @@ def pack_rows(w2d: torch.Tensor, dtype, kp=None) -> torch.Tensor:
     return out
 
 
-def pack_transpose(w3d: torch.Tensor, dtype, out=None, ldo=None, col0=0) -> torch.Tensor:
-    """[N][T][C] fp32 -> out[c][col0 + t*N + n] T (the data-gradient operand; row stride ldo)."""
+def pack_transpose(w3d: torch.Tensor, dtype, out=None, ldo=None, col0=0, flip=False) -> torch.Tensor:
+    """[N][T][C] fp32 -> out[c][col0 + t*N + n] T (the data-gradient operand; row stride ldo; flip reverses the taps)."""
     n, t, c = w3d.shape
     if out is None:
         out = torch.empty((c, t, n), device=w3d.device, dtype=dtype)
         ldo = t * n
-    call("vqa_pack_transpose", dt(dtype), ptr(w3d), ptr(out), n, t, c, ldo, col0)
+    call("vqa_pack_transpose", dt(dtype), ptr(w3d), ptr(out), n, t, c, ldo, col0, int(flip))
     return out
+
+
+def c64_blocks(B, H, W) -> int:
+    return L.count("vqa_conv3x3_c64_blocks", B, H, W)
+
+
+def conv3x3_c64(x, w, B, H, W, *, want_stats=False, addend=None, addmask=None):
+    """bf16 3x3/1 conv, 64->64 channels, LDS-patch kernel.  Returns (out [B*H*W, 64], stats slab | None, blocks)."""
+    nb = c64_blocks(B, H, W)
+    out = torch.empty((B * H * W, 64), device=x.device, dtype=torch.bfloat16)
+    stats = torch.empty((nb, 2, 64), device=x.device, dtype=torch.float32) if want_stats else None
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_conv3x3_c64", ptr(x), ptr(w), ptr(out), ptr(stats), ptr(addend), ptr(addmask), B, H, W)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("conv3x3_c64_kernel", 2.0 * B * H * W * 64 * 576, e0, e1))
+    return out, stats, nb
+
+
+def wgrad3x3_c64(x, dy, dw, B, H, W):
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_wgrad3x3_c64", ptr(x), ptr(dy), ptr(dw), B, H, W)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("wgrad3x3_c64_kernel", 2.0 * B * H * W * 64 * 576, e0, e1))
 
 
 def dgrad_s2(dy, dyd, wt, B, H, W, C, Ho, Wo, N, R, pad, *, dtype):
