@@ -52,3 +52,16 @@ for name, Cin, Cout, H, R, stride, pad in CONVS:
     print(f"{name:22s} dgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
     t = timeit(lambda: K.wgrad(dy, x, dw, M, Cout, Kw, geom, dtype=T), args.iters)
     print(f"{name:22s} wgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
+
+if not args.only or "c64" in args.only:
+    H = 56
+    x = torch.randn(B * H * H, 64, device=dev).to(T)
+    w = torch.randn(64, 576, device=dev) * 0.05
+    dy = torch.randn(B * H * H, 64, device=dev).to(T)
+    wp = K.pack_rows(w, T)
+    dw = torch.zeros(64, 576, device=dev)
+    fl = 2.0 * B * H * H * 64 * 576
+    t = timeit(lambda: K.conv3x3_c64(x, wp, B, H, H, want_stats=True), args.iters)
+    print(f"c64 patch conv fwd     {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   io {(2*x.numel())*2/t/1e12:5.2f} TB/s")
+    t = timeit(lambda: K.wgrad3x3_c64(x, dy, dw, B, H, H), args.iters)
+    print(f"c64 patch wgrad        {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")

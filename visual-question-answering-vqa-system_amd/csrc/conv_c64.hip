@@ -11,7 +11,8 @@
 #include "common.h"
 
 namespace {
-constexpr int RBC = 2;            // output rows per block
+constexpr int RBF = 2;            // output rows per block, forward / data gradient
+constexpr int RBG = 4;            // output rows per block, weight gradient
 constexpr int CH = 64;            // channels (in and out)
 constexpr int LDE = 32 + 8;       // epilogue staging row stride (elements)
 constexpr int OOBV = (int)0x80000000;
@@ -27,18 +28,18 @@ struct C64Params {
   int B, H, W; unsigned x_bytes;
 };
 
-__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
+__global__ __launch_bounds__(256) void conv3x3_c64_kernel(C64Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PWc = p.W + 2;
-  const int patch_elems = (RBC + 2) * PWc * CH;
+  const int patch_elems = (RBF + 2) * PWc * CH;
   bf16_t* patch0 = reinterpret_cast<bf16_t*>(smem);
   bf16_t* patch1 = patch0 + patch_elems;
   bf16_t* Est = patch1 + patch_elems;                       // [4 waves][16][LDE]
   float* red = reinterpret_cast<float*>(Est + 4 * 16 * LDE); // [2 m-waves][64][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int wn = wave & 1, wm = wave >> 1;                   // wave owns channels [32*wn, 32*wn+32), m tiles wm, wm+2, ...
-  const int rblocks = p.H / RBC, nblocks = p.B * rblocks;
-  const int mtiles = RBC * p.W / 16;
+  const int rblocks = p.H / RBF, nblocks = p.B * rblocks;
+  const int mtiles = RBF * p.W / 16;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, (int)p.x_bytes, 0x00020000);
 
   // ---- weight fragments: w[n][(r,s,c)] (576 per row), resident for the whole launch
@@ -49,33 +50,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     for (int nt = 0; nt < 2; ++nt)
       bfr[kk][nt] = *reinterpret_cast<const bf16x8*>(p.w + (size_t)(wn * 32 + nt * 16 + li) * 576 + kk * 32 + g * 8);
 
-  // ---- patch staging: chunk id -> (prow, pcol, chunk); <= 8 chunks per thread
+  // ---- patch staging descriptors, computed once: chunk id -> LDS offset, offset relative to the block's first pixel,
+  //      patch row (for the per-block vertical range check).  No integer division inside the block loop.
   constexpr int MAXV = 8;
-  const int nchunks = (RBC + 2) * PWc * 8;
+  const int nchunks = (RBF + 2) * PWc * 8;
+  const float inv_pw = 1.0f / (float)PWc, inv_w = 1.0f / (float)p.W;
+  int s_lds[MAXV], s_rel[MAXV]; unsigned long long s_prow = 0;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int id = tid + 256 * i;
+    s_lds[i] = -1; s_rel[i] = OOBV;
+    if (id < nchunks) {
+      const int chunk = id & 7, q = id >> 3, prow = (int)(((float)q + 0.5f) * inv_pw), pcol = q - prow * PWc;
+      s_lds[i] = patch_off(prow, pcol, chunk, PWc);
+      const int iw = pcol - 1;
+      if ((unsigned)iw < (unsigned)p.W) s_rel[i] = (((prow - 1) * p.W + iw) * CH + chunk * 8) * 2;
+      s_prow |= (unsigned long long)prow << (4 * i);
+    }
+  }
   u32x4 pre[MAXV];
   auto pload = [&](int blk) {
-    const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBC;
+    const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBF;
+    const int base = ((b * p.H + oh0) * p.W) * CH * 2;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int id = tid + 256 * i;
-      int off = OOBV;
-      if (id < nchunks) {
-        const int chunk = id & 7, q = id >> 3, pcol = q % PWc, prow = q / PWc;
-        const int ih = oh0 - 1 + prow, iw = pcol - 1;
-        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) off = (((b * p.H + ih) * p.W + iw) * CH + chunk * 8) * 2;
-      }
+      const int ih = oh0 - 1 + (int)((s_prow >> (4 * i)) & 15);
+      const int off = ((unsigned)ih < (unsigned)p.H && s_rel[i] != OOBV) ? base + s_rel[i] : OOBV;
       pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
     }
   };
   auto pstore = [&](bf16_t* dst) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int id = tid + 256 * i;
-      if (id < nchunks) {
-        const int chunk = id & 7, q = id >> 3, pcol = q % PWc, prow = q / PWc;
-        *reinterpret_cast<u32x4*>(dst + patch_off(prow, pcol, chunk, PWc)) = pre[i];
-      }
-    }
+    for (int i = 0; i < MAXV; ++i)
+      if (s_lds[i] >= 0) *reinterpret_cast<u32x4*>(dst + s_lds[i]) = pre[i];
   };
 
   float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
@@ -87,14 +94,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
     const int nxt = blk + gridDim.x;
     if (nxt < nblocks) pload(nxt);
     const bf16_t* pt = buf ? patch1 : patch0;
-    const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBC;
+    const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBF;
     for (int mt = wm; mt < mtiles; mt += 2) {
-      const int px = mt * 16 + li, orow = px / p.W, ow = px - orow * p.W;
+      const int px = mt * 16 + li, orow = (int)(((float)px + 0.5f) * inv_w), ow = px - orow * p.W;
+      // per-tile address terms: e[s][half] = offset of (row orow, col ow+s, swizzled chunk half*4+g); taps add r*PWc*64
+      int e[3][2];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int col = ow + s, cb = (orow * PWc + col) * 64;
+        e[s][0] = cb + ((g ^ (col & 7)) << 3);
+        e[s][1] = cb + (((4 + g) ^ (col & 7)) << 3);
+      }
+      const int rowstep = PWc * 64;
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int kk = 0; kk < 18; ++kk) {
-        const int tap = kk >> 1, r = tap / 3, s = tap - r * 3, chunk = (kk & 1) * 4 + g;
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(pt + patch_off(orow + r, ow + s, chunk, PWc));
+        const int tap = kk >> 1, r = tap / 3, s = tap - r * 3;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(pt + e[s][kk & 1] + r * rowstep);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[kk][0], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[kk][1], acc[1], 0, 0, 0);
       }
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       {
         const int pxl = lane >> 2, cv = lane & 3;
-        const int pxo = mt * 16 + pxl, orow2 = pxo / p.W, ow2 = pxo - orow2 * p.W;
+        const int pxo = mt * 16 + pxl, orow2 = (int)(((float)pxo + 0.5f) * inv_w), ow2 = pxo - orow2 * p.W;
         const size_t off = (((size_t)b * p.H + oh0 + orow2) * p.W + ow2) * CH + wn * 32 + cv * 8;
         Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(&myst[pxl * LDE + cv * 8]);
         if (p.addend) {
@@ -152,17 +168,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(C64Params p) {
 // ------------------------------------------------------------------------------------------------
 struct C64WgradParams { const bf16_t* x; const bf16_t* dy; float* dw; int B, H, W; unsigned x_bytes, dy_bytes; };
 
-__global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(C64WgradParams p) {
+__global__ __launch_bounds__(256) void wgrad3x3_c64_kernel(C64WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int LDD = CH + 4;
   const int PWc = p.W + 2;
-  const int patch_elems = (RBC + 2) * PWc * CH;
-  const int MP = (RBC * p.W + 31) / 32 * 32;                 // pixels per block padded to the MFMA K step
+  const int patch_elems = (RBG + 2) * PWc * CH;
+  const int MP = (RBG * p.W + 31) / 32 * 32;                 // pixels per block padded to the MFMA K step
   bf16_t* patch = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Dy = patch + patch_elems;                           // [MP][LDD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int q = li >> 2, pp = li & 3;
-  const int rblocks = p.H / RBC, nblocks = p.B * rblocks, npx = RBC * p.W;
+  const int rblocks = p.H / RBG, nblocks = p.B * rblocks, npx = RBG * p.W;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
   for (int i = tid; i < (MP - npx) * LDD; i += 256) Dy[npx * LDD + i] = 0;      // padded pixel rows stay zero
@@ -173,37 +189,42 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(C64WgradParams p) 
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int MAXV = 8, MAXD = 4;
-  const int nchunks = (RBC + 2) * PWc * 8, ndy = npx * 8;
+  constexpr int MAXV = 12, MAXD = 8;
+  const int nchunks = (RBG + 2) * PWc * 8, ndy = npx * 8;
+  const float inv_pw = 1.0f / (float)PWc, inv_w = 1.0f / (float)p.W;
+  int s_lds[MAXV], s_rel[MAXV]; unsigned long long s_prow = 0;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int id = tid + 256 * i;
+    s_lds[i] = -1; s_rel[i] = OOBV;
+    if (id < nchunks) {
+      const int chunk = id & 7, qq = id >> 3, prow = (int)(((float)qq + 0.5f) * inv_pw), pcol = qq - prow * PWc;
+      s_lds[i] = patch_off(prow, pcol, chunk, PWc);
+      const int iw = pcol - 1;
+      if ((unsigned)iw < (unsigned)p.W) s_rel[i] = (((prow - 1) * p.W + iw) * CH + chunk * 8) * 2;
+      s_prow |= (unsigned long long)prow << (4 * i);
+    }
+  }
   u32x4 pre[MAXV], prd[MAXD];
   auto gload = [&](int blk) {
-    const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBC;
+    const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBG;
+    const int base = ((b * p.H + oh0) * p.W) * CH * 2;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-      const int id = tid + 256 * i;
-      int off = OOBV;
-      if (id < nchunks) {
-        const int chunk = id & 7, qq = id >> 3, pcol = qq % PWc, prow = qq / PWc;
-        const int ih = oh0 - 1 + prow, iw = pcol - 1;
-        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) off = (((b * p.H + ih) * p.W + iw) * CH + chunk * 8) * 2;
-      }
+      const int ih = oh0 - 1 + (int)((s_prow >> (4 * i)) & 15);
+      const int off = ((unsigned)ih < (unsigned)p.H && s_rel[i] != OOBV) ? base + s_rel[i] : OOBV;
       pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < MAXD; ++i) {
       const int id = tid + 256 * i;
-      prd[i] = __builtin_amdgcn_raw_buffer_load_b128(rsY, id < ndy ? (((b * p.H + oh0) * p.W) * CH + id * 8) * 2 : OOBV, 0, 0);
+      prd[i] = __builtin_amdgcn_raw_buffer_load_b128(rsY, id < ndy ? base + id * 16 : OOBV, 0, 0);
     }
   };
   auto sstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int id = tid + 256 * i;
-      if (id < nchunks) {
-        const int chunk = id & 7, qq = id >> 3, pcol = qq % PWc, prow = qq / PWc;
-        *reinterpret_cast<u32x4*>(patch + patch_off(prow, pcol, chunk, PWc)) = pre[i];
-      }
-    }
+    for (int i = 0; i < MAXV; ++i)
+      if (s_lds[i] >= 0) *reinterpret_cast<u32x4*>(patch + s_lds[i]) = pre[i];
 #pragma unroll
     for (int i = 0; i < MAXD; ++i) {
       const int id = tid + 256 * i;
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_c64_kernel(C64WgradParams p) 
       // pixel rows this lane addresses for the transposed reads (clamped inside the block for the zero-padded tail)
       int pxa = ks * 32 + 8 * g + q, pxb = pxa + 4;
       pxa = pxa < npx ? pxa : npx - 1; pxb = pxb < npx ? pxb : npx - 1;
-      const int ra = pxa / p.W, ca = pxa - ra * p.W, rb = pxb / p.W, cb = pxb - rb * p.W;
+      const int ra = (int)(((float)pxa + 0.5f) * inv_w), ca = pxa - ra * p.W, rb = (int)(((float)pxb + 0.5f) * inv_w), cb = pxb - rb * p.W;
       const int chunk = wave * 2 + (pp >> 1), sub = (pp & 1) * 4;             // columns 16*wave + 4*pp .. +3
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -265,9 +286,9 @@ extern "C" {
 
 // persistent grid size (= rows of the BN statistics slab) or 0 when the shape is unsupported
 int vqa_conv3x3_c64_blocks(int B, int H, int W) {
-  if (H % RBC || (RBC * W) % 16 || W > 126 || B * (H / RBC) <= 0) return 0;
-  if (((RBC + 2) * (W + 2) * 8 + 255) / 256 > 8) return 0;
-  const int nb = B * (H / RBC);
+  if (H % RBG || (RBF * W) % 16 || W > 126 || B * (H / RBG) <= 0) return 0;
+  if (((RBF + 2) * (W + 2) * 8 + 255) / 256 > 8 || ((RBG + 2) * (W + 2) * 8 + 255) / 256 > 12 || (RBG * W * 8 + 255) / 256 > 8) return 0;
+  const int nb = B * (H / RBG);
   return nb < 512 ? nb : 512;
 }
 // x NHWC bf16 [B][H][W][64]; w [64][(r,s,c)] bf16 (forward: [Cout][R][S][Cin]; data gradient: flipped+transposed pack);
@@ -282,7 +303,7 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb;
-  const size_t shm = (size_t)2 * (RBC + 2) * (W + 2) * CH * 2 + 4 * 16 * LDE * 2 + 2 * 64 * 2 * 4;
+  const size_t shm = (size_t)2 * (RBF + 2) * (W + 2) * CH * 2 + 4 * 16 * LDE * 2 + 2 * 64 * 2 * 4;
   static size_t attr = 0;
   if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
   hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), shm, st, p);
@@ -291,14 +312,14 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
 // dw [64][576] fp32 (+=)
 int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int W, hipStream_t st) {
   const int grid = vqa_conv3x3_c64_blocks(B, H, W);
-  if (!x || !dy || !dw || grid <= 0 || (RBC * W * 8 + 255) / 256 > 4) return VQA_EARG;
+  if (!x || !dy || !dw || grid <= 0) return VQA_EARG;
   C64WgradParams p;
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.B = B; p.H = H; p.W = W;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)xb;
-  const int MP = (RBC * W + 31) / 32 * 32;
-  const size_t shm = (size_t)(RBC + 2) * (W + 2) * CH * 2 + (size_t)MP * (CH + 4) * 2;
+  const int MP = (RBG * W + 31) / 32 * 32;
+  const size_t shm = (size_t)(RBG + 2) * (W + 2) * CH * 2 + (size_t)MP * (CH + 4) * 2;
   static size_t attr = 0;
   if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
   hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(grid), dim3(256), shm, st, p);
