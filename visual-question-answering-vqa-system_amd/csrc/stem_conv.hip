@@ -45,12 +45,20 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     *reinterpret_cast<u32x4*>(&Wl[n * LDW + kv * 8]) = *reinterpret_cast<const u32x4*>(&wst[n * KP + kv * 8]);
   }
   const int ih_base = 2 * oh0 - 3;
-  for (int i = tid; i < 3 * PR * PW; i += 256) {
-    const int x = i % PW, q = i / PW, pr = q % PR, c = q / PR;
-    const int ih = ih_base + pr, iw = x - 3;
-    float v = 0.f;
-    if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = img[((size_t)(b * 3 + c) * H + ih) * W + iw];
-    patch[i] = f2bf(v);
+  for (int x = tid; x < PW; x += 256) {                    // lanes walk x (coalesced); all 3*PR row loads are issued
+    const int iw = x - 3;                                    // back to back before the first use (latency overlapped)
+    const bool cok = iw >= 0 && iw < W;
+    float vals[3 * PR];
+#pragma unroll
+    for (int row = 0; row < 3 * PR; ++row) {
+      const int c = row / PR, pr = row - c * PR, ih = ih_base + pr;
+      const bool ok = cok && ih >= 0 && ih < H;
+      const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);      // always-valid address: unconditional load
+      const float t = img[((size_t)(b * 3 + c) * H + ihc) * W + iwc];
+      vals[row] = ok ? t : 0.f;
+    }
+#pragma unroll
+    for (int row = 0; row < 3 * PR; ++row) patch[row * PW + x] = f2bf(vals[row]);
   }
   __syncthreads();
 
@@ -158,12 +166,20 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBW;
     __syncthreads();                                                 // previous block's readers are done with the patch
     const int ih_base = 2 * oh0 - 3;
-    for (int i = tid; i < 3 * PRW * PW; i += 256) {
-      const int x = i % PW, qq = i / PW, pr = qq % PRW, c = qq / PRW;
-      const int ih = ih_base + pr, iw = x - 3;
-      float v = 0.f;
-      if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = img[((size_t)(b * 3 + c) * H + ih) * W + iw];
-      patch[i] = f2bf(v);
+    for (int x = tid; x < PW; x += 256) {
+      const int iw = x - 3;
+      const bool cok = iw >= 0 && iw < W;
+      float vals[3 * PRW];
+#pragma unroll
+      for (int row = 0; row < 3 * PRW; ++row) {
+        const int c = row / PRW, pr = row - c * PRW, ih = ih_base + pr;
+        const bool ok = cok && ih >= 0 && ih < H;
+        const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+        const float t = img[((size_t)(b * 3 + c) * H + ihc) * W + iwc];
+        vals[row] = ok ? t : 0.f;
+      }
+#pragma unroll
+      for (int row = 0; row < 3 * PRW; ++row) patch[row * PW + x] = f2bf(vals[row]);
     }
     for (int orow = 0; orow < RBW; ++orow) {
       __syncthreads();                                               // patch ready / previous row's MFMA reads done
@@ -175,15 +191,17 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[px * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned
         d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
       }
-      for (int v = tid; v < Wo * 24; v += 256) {
-        const int px = v / 24, pair = v - px * 24;
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (pair < 21) {
-          const int c = pair / 7, r = pair - c * 7;
-          const uint32_t* ap = reinterpret_cast<const uint32_t*>(&patch[(c * PRW + 2 * orow + r) * PW + 2 * px]);
-          val = u32x4{ap[0], ap[1], ap[2], ap[3] & 0x0000ffffu};     // s8 = 7 is padding
+      if (tid < 240) {                                               // 10 pixels x 24 (c,r) pairs per pass
+        const int pair = tid % 24, c = pair / 7, r = pair - c * 7;
+        const bf16_t* prow = patch + (c * PRW + 2 * orow + r) * PW;
+        for (int px = tid / 24; px < Wo; px += 10) {
+          u32x4 val = {0u, 0u, 0u, 0u};
+          if (pair < 21) {
+            const uint32_t* ap = reinterpret_cast<const uint32_t*>(prow + 2 * px);
+            val = u32x4{ap[0], ap[1], ap[2], ap[3] & 0x0000ffffu};   // s8 = 7 is padding
+          }
+          *reinterpret_cast<u32x4*>(&Acol[px * LDA + pair * 8]) = val;
         }
-        *reinterpret_cast<u32x4*>(&Acol[px * LDA + pair * 8]) = val;
       }
       __syncthreads();
       typedef __attribute__((ext_vector_type(8))) short i16x8;
