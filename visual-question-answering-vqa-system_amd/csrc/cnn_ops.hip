@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     sc[j] = coef[c0 + j]; sh[j] = coef[C + c0 + j];
     rs[j] = rcoef ? rcoef[c0 + j] : 1.f; rh[j] = rcoef ? rcoef[C + c0 + j] : 0.f;
   }
+#pragma unroll 2
   for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
     const size_t off = r * C + c0;
     Vec16<T> v = ldg16(y + off), rr, o;
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   for (int j = 0; j < VEC; ++j) sg[j] = sx[j] = sx2[j] = 0.f;
   if (myr < lanes_r) {
     const int c0 = myv * VEC;
+#pragma unroll 2
     for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
       const size_t off = r * C + c0;
       Vec16<T> d = ldg16(dout + off), yy = ldg16(y + off), o, y2v;
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     a[j] = bc[c0 + j]; b[j] = bc[C + c0 + j]; c[j] = bc[2 * C + c0 + j];
     a2[j] = y2 ? bc2[c0 + j] : 0.f; b2[j] = y2 ? bc2[C + c0 + j] : 0.f; c2[j] = y2 ? bc2[2 * C + c0 + j] : 0.f;
   }
+#pragma unroll 2
   for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
     const size_t off = r * C + c0;
     Vec16<T> d = ldg16(dout + off), yy = ldg16(y + off), o, y2v, rr, r2;
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(256) void spatial_wgrad_kernel(const float* __restr
   const int o = blockIdx.x, ch = o / 49, r = (o % 49) / 7, s = o % 7;
   float t = 0.f;
   const size_t n = (size_t)B * H * W;
-  for (size_t i = threadIdx.x; i < n; i += 256) {
+  for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (size_t)gridDim.y * 256) {
     const int ww = (int)(i % W); size_t q = i / W; const int h = (int)(q % H); const int b = (int)(q / H);
     const int ih = h + r - 3, iw = ww + s - 3;
     if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(256) void spatial_wgrad_kernel(const float* __restr
   t = wave_sum(t);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
   __syncthreads();
-  if (threadIdx.x == 0) dw[o] += sh[0] + sh[1] + sh[2] + sh[3];
+  if (threadIdx.x == 0) atomicAdd(dw + o, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 // NHWC(T) <-> NCHW(fp32) boundary conversions (aux['image_features'] is NCHW fp32 at the API boundary)
@@ -725,7 +728,7 @@ int vqa_spatial_bwd(int dtype, const void* dout, const void* x, const float* w, 
   const size_t nvec = npix * C / VEC;
   DT(hipLaunchKernelGGL(spatial_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)dout, amap, dpool2, amax, (float*)dx, nvec, C),
      hipLaunchKernelGGL(spatial_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)dout, amap, dpool2, amax, (bf16_t*)dx, nvec, C));
-  hipLaunchKernelGGL(spatial_wgrad_kernel, dim3(98), dim3(256), 0, st, dpre, pooled2, dw, B, H, W);
+  hipLaunchKernelGGL(spatial_wgrad_kernel, dim3(98, 16), dim3(256), 0, st, dpre, pooled2, dw, B, H, W);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 

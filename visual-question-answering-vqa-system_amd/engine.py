@@ -125,6 +125,35 @@ class HipEngine:
                             bias=self.P(bname) if bname else None, relu=relu, drop_p=p, drop_seed=seed, addend=addend)
         return out
 
+    def _lin_multi(self, x, wnames):
+        """One GEMM over several bias-free Linear weights that sit back to back in the flat buffer ([sum N][K] view)."""
+        e0 = self.E[wnames[0]]
+        Kin = e0.shape[1]
+        N = sum(self.E[w].shape[0] for w in wnames)
+        M = x.shape[0]
+        w = self.wsrc[e0.offset: e0.offset + N * Kin].view(N, Kin)
+        out, _, _ = K.igemm(x, w, M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype)
+        return out
+
+    def _lin_multi_bwd(self, dz, x_in, wnames, G, addend=None):
+        e0 = self.E[wnames[0]]
+        Kin = e0.shape[1]
+        N = sum(self.E[w].shape[0] for w in wnames)
+        M = dz.shape[0]
+        K.wgrad(dz, x_in, G[e0.offset: e0.offset + N * Kin].view(N, Kin), M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype)
+        key = wnames[0] + ".multiT"
+        wt = self._wt.get(key)
+        if wt is None:
+            wt = K.pack_transpose(self.flat[e0.offset: e0.offset + N * Kin].view(N, 1, Kin), self.dtype)
+            self._wt[key] = wt
+        dx, _, _ = K.igemm(dz, wt, M, Kin, N, K.linear_geom(M, N), dtype=self.dtype, addend=addend)
+        return dx
+
+    def _adjacent(self, wnames):
+        es = [self.E[w] for w in wnames]
+        return all(es[i].offset + es[i].numel == es[i + 1].offset and es[i].shape[1] == es[0].shape[1] for i in range(len(es) - 1)) \
+            and all(e.shape[0] % 8 == 0 for e in es)
+
     def _lin_bwd(self, dz, x_in, wname, G, need_dx=True, addend=None):
         """dW += dz^T x ; returns dx = dz W (+ addend)."""
         e = self.E[wname]
@@ -345,13 +374,21 @@ class HipEngine:
             nkv, stkv = nq, None
         else:
             nkv, stkv = self._ln(kv_in, norm_kv)
-        Q = self._lin(nq, attn + ".W_q.weight")
-        Kt = self._lin(nkv, attn + ".W_k.weight")
-        V = self._lin(nkv, attn + ".W_v.weight")
+        wq, wk, wv = attn + ".W_q.weight", attn + ".W_k.weight", attn + ".W_v.weight"
+        fused = self._adjacent([wq, wk, wv]) if self_attn else self._adjacent([wk, wv])
+        if fused and self_attn:                       # one [M][3d] GEMM; Q/K/V are column slices (row stride 3d)
+            qkv = self._lin_multi(nq, [wq, wk, wv])
+            Q, Kt, V, ldq, ldkv = qkv, qkv[:, d:], qkv[:, 2 * d:], 3 * d, 3 * d
+        elif fused:
+            Q = self._lin(nq, wq)
+            kv = self._lin_multi(nkv, [wk, wv])
+            Kt, V, ldq, ldkv = kv, kv[:, d:], d, 2 * d
+        else:
+            Q, Kt, V, ldq, ldkv = self._lin(nq, wq), self._lin(nkv, wk), self._lin(nkv, wv), d, d
         probs = torch.empty((B, heads, Lq, Lk), device=Q.device, dtype=torch.float32)
         ctx = torch.empty((B * Lq, d), device=Q.device, dtype=T)
         sa = self._seed()
-        call("vqa_attention_fwd", dt(T), ptr(Q), ptr(Kt), ptr(V), d, d, d, ptr(kmask), ptr(probs), ptr(ctx), d, B, heads, Lq, Lk, hd,
+        call("vqa_attention_fwd", dt(T), ptr(Q), ptr(Kt), ptr(V), ldq, ldkv, ldkv, ptr(kmask), ptr(probs), ptr(ctx), d, B, heads, Lq, Lk, hd,
              float(p), sa)
         so = self._seed()
         x1 = self._lin(ctx, attn + ".W_o.weight", p=p, seed=so, addend=q_in)
@@ -359,7 +396,8 @@ class HipEngine:
         s1, s2 = self._seed(), self._seed()
         h = self._lin(nf, fc1 + ".weight", fc1 + ".bias", relu=1, p=p, seed=s1)
         out = self._lin(h, fc2 + ".weight", fc2 + ".bias", p=p, seed=s2, addend=x1)
-        return dict(q_in=q_in, kv_in=kv_in, nq=nq, stq=stq, nkv=nkv, stkv=stkv, Q=Q, K=Kt, V=V, probs=probs, ctx=ctx, sa=sa, so=so,
+        return dict(q_in=q_in, kv_in=kv_in, nq=nq, stq=stq, nkv=nkv, stkv=stkv, Q=Q, K=Kt, V=V, ldq=ldq, ldkv=ldkv, fused=fused,
+                    probs=probs, ctx=ctx, sa=sa, so=so,
                     x1=x1, nf=nf, stf=stf, h=h, s1=s1, s2=s2, out=out, p=p, norm_q=norm_q, norm_kv=norm_kv, attn=attn, norm_f=norm_f,
                     fc1=fc1, fc2=fc2, self_attn=self_attn, B=B, Lq=Lq, Lk=Lk, heads=heads, hd=hd)
 
@@ -376,17 +414,35 @@ class HipEngine:
         dx1 = self._ln_bwd(dnf, rec["x1"], rec["norm_f"], rec["stf"], G, addend=dout)
         dzo = self._act_bwd(dx1, None, None, G, p, rec["so"])
         dctx = self._lin_bwd(dzo, rec["ctx"], attn + ".W_o.weight", G)
-        dQ = torch.empty_like(rec["Q"]); dK = torch.empty_like(rec["K"]); dV = torch.empty_like(rec["V"])
-        call("vqa_attention_bwd", dt(T), ptr(dctx), d, ptr(rec["Q"]), ptr(rec["K"]), ptr(rec["V"]), d, d, d, ptr(rec["probs"]),
-             ptr(dQ), ptr(dK), ptr(dV), d, d, d, B, heads, Lq, Lk, hd, float(p), rec["sa"])
-        dnq = self._lin_bwd(dQ, rec["nq"], attn + ".W_q.weight", G)
+        wq, wk, wv = attn + ".W_q.weight", attn + ".W_k.weight", attn + ".W_v.weight"
+        ldq, ldkv, fused = rec["ldq"], rec["ldkv"], rec["fused"]
+        dev = dctx.device
+        if fused and rec["self_attn"]:
+            dqkv = torch.empty((B * Lq, 3 * d), device=dev, dtype=T)
+            dQ, dK, dV = dqkv, dqkv[:, d:], dqkv[:, 2 * d:]
+        elif fused:
+            dQ = torch.empty((B * Lq, d), device=dev, dtype=T)
+            dkv = torch.empty((B * Lk, 2 * d), device=dev, dtype=T)
+            dK, dV = dkv, dkv[:, d:]
+        else:
+            dQ = torch.empty((B * Lq, d), device=dev, dtype=T); dK = torch.empty((B * Lk, d), device=dev, dtype=T); dV = torch.empty((B * Lk, d), device=dev, dtype=T)
+        call("vqa_attention_bwd", dt(T), ptr(dctx), d, ptr(rec["Q"]), ptr(rec["K"]), ptr(rec["V"]), ldq, ldkv, ldkv, ptr(rec["probs"]),
+             ptr(dQ), ptr(dK), ptr(dV), ldq, ldkv, ldkv, B, heads, Lq, Lk, hd, float(p), rec["sa"])
         if rec["self_attn"]:
-            dnq = self._lin_bwd(dK, rec["nkv"], attn + ".W_k.weight", G, addend=dnq)
-            dnq = self._lin_bwd(dV, rec["nkv"], attn + ".W_v.weight", G, addend=dnq)
+            if fused:
+                dnq = self._lin_multi_bwd(dqkv, rec["nq"], [wq, wk, wv], G)
+            else:
+                dnq = self._lin_bwd(dQ, rec["nq"], wq, G)
+                dnq = self._lin_bwd(dK, rec["nkv"], wk, G, addend=dnq)
+                dnq = self._lin_bwd(dV, rec["nkv"], wv, G, addend=dnq)
             dq_in = self._ln_bwd(dnq, rec["q_in"], rec["norm_q"], rec["stq"], G, addend=dx1)
             return dq_in, None
-        dnkv = self._lin_bwd(dK, rec["nkv"], attn + ".W_k.weight", G)
-        dnkv = self._lin_bwd(dV, rec["nkv"], attn + ".W_v.weight", G, addend=dnkv)
+        dnq = self._lin_bwd(dQ, rec["nq"], wq, G)
+        if fused:
+            dnkv = self._lin_multi_bwd(dkv, rec["nkv"], [wk, wv], G)
+        else:
+            dnkv = self._lin_bwd(dK, rec["nkv"], wk, G)
+            dnkv = self._lin_bwd(dV, rec["nkv"], wv, G, addend=dnkv)
         dq_in = self._ln_bwd(dnq, rec["q_in"], rec["norm_q"], rec["stq"], G, addend=dx1)
         dkv_in = self._ln_bwd(dnkv, rec["kv_in"], rec["norm_kv"], rec["stkv"], G, addend=dkv_addend)
         return dq_in, dkv_in
