@@ -119,20 +119,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // head h occupies columns [h*hd, (h+1)*hd).  probs [B][H][Lq][Lk] fp32 holds softmax BEFORE dropout.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                       int ldq, int ldk, int ldv, const float* __restrict__ kmask, float* __restrict__ probs,
                                                       T* __restrict__ ctx, int ldc, int H, int Lq, int Lk, int hd, float scale, float p, uint64_t seed) {
   extern __shared__ float sm[];
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H, lane = threadIdx.x, ldh = hd + 1, ldp = Lk + 1;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ldh = hd + 1, ldp = Lk + 1;
   float* Qs = sm; float* Ks = Qs + Lq * ldh; float* Vs = Ks + Lk * ldh; float* Ps = Vs + Lk * ldh;
-  for (int i = lane; i < Lq * hd; i += 64) { const int r = i / hd, d = i - r * hd; Qs[r * ldh + d] = to_f<T>(q[(size_t)(b * Lq + r) * ldq + h * hd + d]); }
-  for (int i = lane; i < Lk * hd; i += 64) {
+  for (int i = tid; i < Lq * hd; i += 256) { const int r = i / hd, d = i - r * hd; Qs[r * ldh + d] = to_f<T>(q[(size_t)(b * Lq + r) * ldq + h * hd + d]); }
+  for (int i = tid; i < Lk * hd; i += 256) {
     const int r = i / hd, d = i - r * hd;
     Ks[r * ldh + d] = to_f<T>(k[(size_t)(b * Lk + r) * ldk + h * hd + d]);
     Vs[r * ldh + d] = to_f<T>(v[(size_t)(b * Lk + r) * ldv + h * hd + d]);
   }
   __syncthreads();
-  for (int i = lane; i < Lq * Lk; i += 64) {
+  for (int i = tid; i < Lq * Lk; i += 256) {
     const int r = i / Lk, c = i - r * Lk;
     float s = 0.f;
     for (int d = 0; d < hd; ++d) s += Qs[r * ldh + d] * Ks[c * ldh + d];
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const T* __restrict__ q, c
   }
   __syncthreads();
   float* pg = probs + ((size_t)(b * H + h) * Lq) * Lk;
-  for (int r = 0; r < Lq; ++r) {
+  for (int r = wave; r < Lq; r += 4) {
     float m = -INFINITY;
     for (int c = lane; c < Lk; c += 64) m = fmaxf(m, Ps[r * ldp + c]);
     m = wave_max(m);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const T* __restrict__ q, c
     }
   }
   __syncthreads();
-  for (int i = lane; i < Lq * hd; i += 64) {
+  for (int i = tid; i < Lq * hd; i += 256) {
     const int r = i / hd, d = i - r * hd;
     float a = 0.f;
     for (int c = 0; c < Lk; ++c) a += Ps[r * ldp + c] * Vs[c * ldh + d];
@@ -166,27 +166,27 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const T* __restrict__ q, c
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const T* __restrict__ dctx, int ldc, const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dctx, int ldc, const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, int ldq, int ldk, int ldv, const float* __restrict__ probs,
                                                       T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, int lddq, int lddk, int lddv,
                                                       int H, int Lq, int Lk, int hd, float scale, float p, uint64_t seed) {
   extern __shared__ float sm[];
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H, lane = threadIdx.x, ldh = hd + 1, ldp = Lk + 1;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ldh = hd + 1, ldp = Lk + 1;
   float* Qs = sm; float* Os = Qs + Lq * ldh; float* Ks = Os + Lq * ldh; float* Vs = Ks + Lk * ldh;
   float* Ps = Vs + Lk * ldh; float* Ds = Ps + Lq * ldp;             // Ps: dropped probs, Ds: dS
-  for (int i = lane; i < Lq * hd; i += 64) {
+  for (int i = tid; i < Lq * hd; i += 256) {
     const int r = i / hd, d = i - r * hd;
     Qs[r * ldh + d] = to_f<T>(q[(size_t)(b * Lq + r) * ldq + h * hd + d]);
     Os[r * ldh + d] = to_f<T>(dctx[(size_t)(b * Lq + r) * ldc + h * hd + d]);
   }
-  for (int i = lane; i < Lk * hd; i += 64) {
+  for (int i = tid; i < Lk * hd; i += 256) {
     const int r = i / hd, d = i - r * hd;
     Ks[r * ldh + d] = to_f<T>(k[(size_t)(b * Lk + r) * ldk + h * hd + d]);
     Vs[r * ldh + d] = to_f<T>(v[(size_t)(b * Lk + r) * ldv + h * hd + d]);
   }
   __syncthreads();
   const float* pg = probs + ((size_t)(b * H + h) * Lq) * Lk;
-  for (int r = 0; r < Lq; ++r) {
+  for (int r = wave; r < Lq; r += 4) {
     float t = 0.f;
     for (int c = lane; c < Lk; c += 64) {
       const float pr = pg[(size_t)r * Lk + c];
@@ -203,13 +203,13 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const T* __restrict__ dctx
     for (int c = lane; c < Lk; c += 64) Ds[r * ldp + c] = pg[(size_t)r * Lk + c] * (Ds[r * ldp + c] - t) / scale;
   }
   __syncthreads();
-  for (int i = lane; i < Lq * hd; i += 64) {
+  for (int i = tid; i < Lq * hd; i += 256) {
     const int r = i / hd, d = i - r * hd;
     float a = 0.f;
     for (int c = 0; c < Lk; ++c) a += Ds[r * ldp + c] * Ks[c * ldh + d];
     dq[(size_t)(b * Lq + r) * lddq + h * hd + d] = from_f<T>(a);
   }
-  for (int i = lane; i < Lk * hd; i += 64) {
+  for (int i = tid; i < Lk * hd; i += 256) {
     const int c = i / hd, d = i - c * hd;
     float a = 0.f, e = 0.f;
     for (int r = 0; r < Lq; ++r) { a += Ds[r * ldp + c] * Qs[r * ldh + d]; e += Ps[r * ldp + c] * Os[r * ldh + d]; }
@@ -418,8 +418,8 @@ int vqa_attention_fwd(int dtype, const void* q, const void* k, const void* v, in
   const float scale = sqrtf((float)hd);
   if (dtype) { if (shm > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); }
   else { if (shm > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); }
-  DT(hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(B * H), dim3(64), shm, st, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, kmask, probs, (float*)ctx, ldc, H, Lq, Lk, hd, scale, p, seed),
-     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(B * H), dim3(64), shm, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, kmask, probs, (bf16_t*)ctx, ldc, H, Lq, Lk, hd, scale, p, seed));
+  DT(hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(B * H), dim3(256), shm, st, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, kmask, probs, (float*)ctx, ldc, H, Lq, Lk, hd, scale, p, seed),
+     hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(B * H), dim3(256), shm, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, kmask, probs, (bf16_t*)ctx, ldc, H, Lq, Lk, hd, scale, p, seed));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_attention_bwd(int dtype, const void* dctx, int ldc, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
@@ -430,8 +430,8 @@ int vqa_attention_bwd(int dtype, const void* dctx, int ldc, const void* q, const
   const float scale = sqrtf((float)hd);
   if (dtype) { if (shm > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); }
   else { if (shm > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); }
-  DT(hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B * H), dim3(64), shm, st, (const float*)dctx, ldc, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, probs, (float*)dq, (float*)dk, (float*)dv, lddq, lddk, lddv, H, Lq, Lk, hd, scale, p, seed),
-     hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, dim3(B * H), dim3(64), shm, st, (const bf16_t*)dctx, ldc, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, H, Lq, Lk, hd, scale, p, seed));
+  DT(hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B * H), dim3(256), shm, st, (const float*)dctx, ldc, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, probs, (float*)dq, (float*)dk, (float*)dv, lddq, lddk, lddv, H, Lq, Lk, hd, scale, p, seed),
+     hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, dim3(B * H), dim3(256), shm, st, (const bf16_t*)dctx, ldc, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, H, Lq, Lk, hd, scale, p, seed));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_masked_pool_fwd(int dtype, const void* x, const float* mask, void* out, int ldo, int col0, int B, int L, int D, hipStream_t st) {
