@@ -128,7 +128,7 @@ int vqa_cross_entropy(int dtype, const void* logits, const long long* targets, f
                       int B, int N, float gscale, hipStream_t stream);
 int vqa_convert(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
 /* clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (training/train.py:204-208,127-132) */
-int vqa_sumsq(const float* g, long long n, float* out, hipStream_t stream);
+int vqa_sumsq(const float* g, long long n, float* out /* >= 2049 floats: [0] result (bit-reproducible), rest scratch */, hipStream_t stream);
 int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, float bias_corr1, float bias_corr2, const float* sumsq, float max_norm, float gscale,
               hipStream_t stream);

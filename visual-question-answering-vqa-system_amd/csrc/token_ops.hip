@@ -339,6 +339,8 @@ __global__ void convert_kernel(const TI* __restrict__ in, TO* __restrict__ out, 
 // ---------------------------------------------------------------------------------------------
 // optimizer tail over flat fp32 buffers
 // ---------------------------------------------------------------------------------------------
+// Deterministic two-stage sum of squares (replicas must compute bit-identical clip factors): per-block partials in a fixed
+// slot each, then one block folds them in a fixed order.  out[0] = result, out[1 .. 1+blocks) = partials.
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* out) {
   float s = 0.f;
   const size_t nv = n / 4;
@@ -351,7 +353,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) out[1 + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(float* out, int nparts) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += out[1 + i];
+  __shared__ float sh[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 // clip_grad_norm_(max_norm) + AdamW (decoupled weight decay), torch semantics (training/train.py:204-208,127-132)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
@@ -486,6 +497,7 @@ int vqa_convert(int dtype_in, int dtype_out, const void* in, void* out, long lon
 int vqa_sumsq(const float* g, long long n, float* out, hipStream_t st) {
   size_t blocks = ((size_t)n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, (size_t)n, out);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, out, (int)blocks);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,

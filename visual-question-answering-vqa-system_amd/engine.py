@@ -33,6 +33,9 @@ class HipEngine:
         self.wsrc = flat
         self._wt: Dict[str, torch.Tensor] = {}
         self.stem_w = None
+        # the text encoder (many tiny, latency-bound launches) runs on its own stream beside the CNN, forward and backward
+        self.side = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+        self.two_streams = True
 
     # ------------------------------------------------------------------ parameter access
     def P(self, name):                       # fp32 master, flat 1-D
@@ -216,6 +219,38 @@ class HipEngine:
         phead = cfg["answer_dropout"] if training else 0.0
         dev = images.device
 
+        # ---- text encoder, A6-A8 (issued first, on the side stream; joined before fusion)
+        main = torch.cuda.current_stream()
+        use_side = self.two_streams and self.side is not None
+        if use_side:
+            ev0 = torch.cuda.Event(); ev0.record(main)
+            self.side.wait_event(ev0)                    # weights cast + everything earlier on main is visible to the side stream
+        with torch.cuda.stream(self.side if use_side else main):
+            d, heads = cfg["embed_dim"], cfg["num_attention_heads"]
+            hd = d // heads
+            Bt, L = token_ids.shape
+            rows = Bt * L
+            pe = self.buf["text_encoder.positional_encoding.pe"]
+            if L > pe.shape[1]:
+                raise RuntimeError(f"sequence length {L} exceeds max_question_length {pe.shape[1]}")
+            emb_e = self.E["text_encoder.token_embedding.weight"]
+            sd0 = self._seed()
+            xt = torch.empty((rows, d), device=dev, dtype=T)
+            call("vqa_embed_fwd", dt(T), ptr(token_ids), ptr(self.P(emb_e.name)), ptr(pe), ptr(xt), rows, L, d, emb_e.shape[0],
+                 math.sqrt(d), float(pdrop), sd0)
+            tape["embed"] = dict(ids=token_ids, seed=sd0, p=pdrop)
+            tape["tlayers"] = []
+            for l in range(cfg["num_transformer_layers"]):
+                p = f"text_encoder.layers.{l}"
+                rec = self._attn_block_fwd(xt, xt, None, p + ".norm1", None, p + ".self_attention", maskf, Bt, L, L, heads, hd, pdrop,
+                                           p + ".norm2", p + ".ffn.fc1", p + ".ffn.fc2", self_attn=True)
+                tape["tlayers"].append(rec)
+                xt = rec["out"]
+            enc, enc_st = self._ln(xt, "text_encoder.final_norm")
+            tape["final_norm"] = dict(x=xt, st=enc_st)
+
+            ev_txt = torch.cuda.Event(); ev_txt.record()
+
         # ---- stem: conv7x7/2 (from the NCHW fp32 image) + BN + ReLU + maxpool, A1
         H1, W1 = (IH + 6 - 7) // 2 + 1, (IW + 6 - 7) // 2 + 1
         M = B * H1 * W1
@@ -283,31 +318,9 @@ class HipEngine:
         ntok = Hf * Wf
         tape["feat"] = dict(Hf=Hf, Wf=Wf, Cf=Cf)
 
-        # ---- text encoder, A6-A8
-        d, heads = cfg["embed_dim"], cfg["num_attention_heads"]
-        hd = d // heads
-        Bt, L = token_ids.shape
-        rows = Bt * L
-        pe = self.buf["text_encoder.positional_encoding.pe"]
-        if L > pe.shape[1]:
-            raise RuntimeError(f"sequence length {L} exceeds max_question_length {pe.shape[1]}")
-        emb_e = self.E["text_encoder.token_embedding.weight"]
-        sd0 = self._seed()
-        xt = torch.empty((rows, d), device=dev, dtype=T)
-        call("vqa_embed_fwd", dt(T), ptr(token_ids), ptr(self.P(emb_e.name)), ptr(pe), ptr(xt), rows, L, d, emb_e.shape[0],
-             math.sqrt(d), float(pdrop), sd0)
-        tape["embed"] = dict(ids=token_ids, seed=sd0, p=pdrop)
-        tape["tlayers"] = []
-        for l in range(cfg["num_transformer_layers"]):
-            p = f"text_encoder.layers.{l}"
-            rec = self._attn_block_fwd(xt, xt, None, p + ".norm1", None, p + ".self_attention", maskf, Bt, L, L, heads, hd, pdrop,
-                                       p + ".norm2", p + ".ffn.fc1", p + ".ffn.fc2", self_attn=True)
-            tape["tlayers"].append(rec)
-            xt = rec["out"]
-        enc, enc_st = self._ln(xt, "text_encoder.final_norm")
-        tape["final_norm"] = dict(x=xt, st=enc_st)
-
         # ---- fusion, A9-A11
+        if use_side:
+            main.wait_event(ev_txt)
         pj = "fusion.image_projector.projection"
         pz = self._lin(feat, pj + ".0.weight", pj + ".0.bias")
         sdp = self._seed()
@@ -495,15 +508,23 @@ class HipEngine:
         dfeat = self._lin_bwd(dpz, rp["feat"], pj + ".0.weight", G)
         seg("fusion")
 
-        # ---- text encoder
-        fn = tape["final_norm"]
-        dx = self._ln_bwd(denc, fn["x"], "text_encoder.final_norm", fn["st"], G)
-        for rec in reversed(tape["tlayers"]):
-            dx, _ = self._attn_block_bwd(rec, dx, G)
-        em = tape["embed"]; emb_e = self.E["text_encoder.token_embedding.weight"]
-        call("vqa_embed_bwd", dt(T), ptr(em["ids"]), ptr(dx), ptr(self._gslice(G, emb_e.name)), dx.shape[0], d, emb_e.shape[0],
-             math.sqrt(d), float(em["p"]), em["seed"])
-        seg("text_encoder")
+        # ---- text encoder backward on the side stream, concurrently with the CNN backward below
+        main = torch.cuda.current_stream()
+        use_side = self.two_streams and self.side is not None
+        if use_side:
+            evf = torch.cuda.Event(); evf.record(main)
+            self.side.wait_event(evf)
+            denc.record_stream(self.side)                 # allocated on main, consumed on the side stream
+        with torch.cuda.stream(self.side if use_side else main):
+            fn = tape["final_norm"]
+            dx = self._ln_bwd(denc, fn["x"], "text_encoder.final_norm", fn["st"], G)
+            for rec in reversed(tape["tlayers"]):
+                dx, _ = self._attn_block_bwd(rec, dx, G)
+            em = tape["embed"]; emb_e = self.E["text_encoder.token_embedding.weight"]
+            call("vqa_embed_bwd", dt(T), ptr(em["ids"]), ptr(dx), ptr(self._gslice(G, emb_e.name)), dx.shape[0], d, emb_e.shape[0],
+                 math.sqrt(d), float(em["p"]), em["seed"])
+            seg("text_encoder")
+            ev_tb = torch.cuda.Event(); ev_tb.record()
 
         # ---- CNN stages (reverse)
         dxc = dfeat
@@ -549,6 +570,8 @@ class HipEngine:
             K.wgrad(dy, st["images"], LY.mat_of(G, self.E["image_encoder.stem.0.weight"]), B * H1 * W1, 64, 147, st["geom"], dtype=T,
                     loader=K.LOADER_STEM)
         seg("image_encoder.stem")
+        if use_side:
+            main.wait_event(ev_tb)
 
     def _block_bwd(self, rec, dout, G, training):
         """ResidualBlock backward (reference forward: models/cnn_backbone.py:164-197)."""

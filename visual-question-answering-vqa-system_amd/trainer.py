@@ -67,7 +67,7 @@ class HipTrainer:
         self.G = torch.zeros_like(flat)
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
-        self.sumsq = torch.zeros(1, device=flat.device, dtype=torch.float32)
+        self.sumsq = torch.zeros(1 + 2048, device=flat.device, dtype=torch.float32)   # [0] = sum of squares, rest: block partials
         self.loss = torch.zeros(1, device=flat.device, dtype=torch.float32)
         self.t = 0
         self.buckets = LY.bucket_ranges(model._entries)
@@ -78,7 +78,6 @@ class HipTrainer:
         """One full train step; returns (loss device scalar, logits fp32)."""
         eng, T = self.engine, self.engine.dtype
         self.G.zero_()
-        self.sumsq.zero_()
         self.loss.zero_()
         maskf = None if attention_mask is None else attention_mask.float()
         logits_f, _, tape = eng.forward(images, token_ids, maskf, True, False, need_tape=True)
@@ -96,4 +95,4 @@ class HipTrainer:
         return self.loss, logits_f
 
     def grad_norm(self) -> torch.Tensor:
-        return self.sumsq.sqrt() / self.world
+        return self.sumsq[:1].sqrt() / self.world
