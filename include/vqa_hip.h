@@ -51,6 +51,9 @@ int vqa_stem_conv_blocks(int B, int H, int W);
 int vqa_stem_pack(const float* w_krsc, void* wstem, hipStream_t stream);
 int vqa_stem_conv(const float* img, const void* wstem, void* out, float* stats, int B, int H, int W, hipStream_t stream);
 int vqa_stem_wgrad(const float* img, const void* dy, float* dw /* [64][7][7][3] += */, int B, int H, int W, hipStream_t stream);
+/* same, with the stem BN+ReLU+MaxPool backward apply fused in: dy is rebuilt per row from y, dpool, idx, coef, bcoef */
+int vqa_stem_wgrad_fused(const float* img, const void* y, const void* dpool, const uint8_t* idx, const float* coef,
+                         const float* bcoef, float* dw, int B, int H, int W, hipStream_t stream);
 
 /* ---- BatchNorm2d (nn.BatchNorm2d defaults; models/cnn_backbone.py:151,158,246,351) -----------------------------
  * coef = scale | shift | mean | invstd (4*C floats).  finalize also updates running_mean/var (momentum, unbiased var)

@@ -30,6 +30,7 @@ SIGNATURES = {
     "vqa_stem_pack": [P, P, P],
     "vqa_stem_conv": [P, P, P, P, I, I, I, P],
     "vqa_stem_wgrad": [P, P, P, I, I, I, P],
+    "vqa_stem_wgrad_fused": [P, P, P, P, P, P, P, I, I, I, P],
     "vqa_bn_stats_finalize": [P, I, I, D, P, P, P, P, P, F, F, P, P, P],
     "vqa_bn_eval_coef": [I, P, P, P, P, F, P, P],
     "vqa_bn_apply": [I, P, P, P, P, P, LL, I, I, P],

@@ -8,6 +8,7 @@
 //   out  : NHWC bf16 [B][Ho][Wo][64]   (raw conv output; BN+ReLU+MaxPool is fused in vqa_stem_pool_fwd)
 //   stats: per-workgroup column sums / sums of squares [gridDim][2][64] for train-mode BatchNorm
 #include "common.h"
+#include "stem_route.h"
 
 namespace {
 constexpr int RB = 4;          // output rows per workgroup
@@ -141,8 +142,13 @@ constexpr int LDA = KP + 8;        // im2col row stride
 constexpr int LDD = 64 + 4;        // dy row stride
 }
 
+// FUSED = true: dy is never materialised -- it is rebuilt per row from the raw conv output y, the pooled gradient + argmax
+// (stem_route) and the BatchNorm backward coefficients (dy = A*g + B*y + C), i.e. vqa_stem_bwd_apply folded into the staging.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy, float* __restrict__ dw,
-                                                         int B, int H, int W, int Ho, int Wo) {
+                                                         int B, int H, int W, int Ho, int Wo, const bf16_t* __restrict__ dpool,
+                                                         const uint8_t* __restrict__ idx, const float* __restrict__ coef,
+                                                         const float* __restrict__ bc, int Hp, int Wp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PW = 2 * Wo + 8;
   const int MP = (Wo + 31) / 32 * 32;                                // pixels per row padded to the MFMA K step
@@ -187,7 +193,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       const bf16_t* dyr = dy + (((size_t)b * Ho + oh0 + orow) * Wo) * 64;
       for (int v = tid; v < Wo * 8; v += 256) {
         const int px = v >> 3, cv = v & 7;
-        const u32x4 val = *reinterpret_cast<const u32x4*>(dyr + (size_t)px * 64 + cv * 8);
+        u32x4 val = *reinterpret_cast<const u32x4*>(dyr + (size_t)px * 64 + cv * 8);      // dy row, or y row when FUSED
+        if (FUSED) {
+          Vec16<bf16_t> yy; yy.raw = val;
+          float g8[8];
+          stem_route<bf16_t>(dpool, idx, yy, coef, b, oh0 + orow, px, cv * 8, 64, Hp, Wp, g8);
+          Vec16<bf16_t> o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.set(j, bc[cv * 8 + j] * g8[j] + bc[64 + cv * 8 + j] * yy.get(j) + bc[128 + cv * 8 + j]);
+          val = o.raw;
+        }
         uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[px * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned
         d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
       }
@@ -278,10 +293,28 @@ int vqa_stem_wgrad(const float* img, const void* dy, float* dw, int B, int H, in
   const size_t shm = (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
   if (shm > 160 * 1024) return VQA_EARG;
   static size_t attr = 0;
-  if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
+  if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
   int nblocks = B * (Ho / RBW);
   int grid = nblocks < 512 ? nblocks : 512;
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)dy, dw, B, H, W, Ho, Wo);
+  hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)dy, dw, B, H, W, Ho, Wo,
+                     (const bf16_t*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+// Fused stem BatchNorm/ReLU/MaxPool backward + weight gradient: dy = A*g + B*y + C is rebuilt on the fly from the raw conv
+// output y [B][Ho][Wo][64], the pooled gradient dpool [B][Hp][Wp][64] + argmax idx, coef (4*64) and bcoef (3*64).
+int vqa_stem_wgrad_fused(const float* img, const void* y, const void* dpool, const uint8_t* idx, const float* coef, const float* bcoef,
+                         float* dw, int B, int H, int W, hipStream_t st) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1, Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+  if (!img || !y || !dpool || !idx || !coef || !bcoef || !dw || Ho % RBW || Wo % 16 || Wo > 256) return VQA_EARG;
+  const int PW = 2 * Wo + 8, MP = (Wo + 31) / 32 * 32;
+  const size_t shm = (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
+  if (shm > 160 * 1024) return VQA_EARG;
+  static size_t attr = 0;
+  if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
+  int nblocks = B * (Ho / RBW);
+  int grid = nblocks < 512 ? nblocks : 512;
+  hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)y, dw, B, H, W, Ho, Wo,
+                     (const bf16_t*)dpool, idx, coef, bcoef, Hp, Wp);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 

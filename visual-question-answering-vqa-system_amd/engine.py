@@ -35,7 +35,9 @@ class HipEngine:
         self.stem_w = None
         # the text encoder (many tiny, latency-bound launches) runs on its own stream beside the CNN, forward and backward
         self.side = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+        self.side2 = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None   # CNN weight gradients (off the critical path)
         self.two_streams = True
+        self.wgrad_stream = True
 
     # ------------------------------------------------------------------ parameter access
     def P(self, name):                       # fp32 master, flat 1-D
@@ -202,6 +204,24 @@ class HipEngine:
         eg, eb = self.E[prefix + ".weight"], self.E[prefix + ".bias"]
         return K.layernorm_bwd(dout, x, self.P(prefix + ".weight"), stats, G[eg.offset: eg.offset + eg.numel],
                                G[eb.offset: eb.offset + eb.numel], addend=addend, drop_p=p, seed=seed, dadd=dadd, period=period)
+
+    def _off_path(self, tensors, fn):
+        """Run fn (a weight-gradient launch) on the second side stream: it only needs `tensors` (already produced on the
+        current stream) and writes its own slice of G, so it may overlap the data-gradient chain."""
+        if not (self.wgrad_stream and self.two_streams and self.side2 is not None):
+            return fn()
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event(); ev.record(cur)
+        self.side2.wait_event(ev)
+        for t in tensors:
+            t.record_stream(self.side2)
+        with torch.cuda.stream(self.side2):
+            fn()
+
+    def _join_off_path(self):
+        if self.wgrad_stream and self.two_streams and self.side2 is not None:
+            ev = torch.cuda.Event(); ev.record(self.side2)
+            torch.cuda.current_stream().wait_event(ev)
 
     def _gslice(self, G, name):
         e = self.E[name]
@@ -550,6 +570,8 @@ class HipEngine:
                 dxc = dxn
             for rec in reversed(srec["blocks"]):
                 dxc = self._block_bwd(rec, dxc, G, training)
+            if on_segment is not None:
+                self._join_off_path()
             seg(f"image_encoder.stage{s}")
 
         # ---- stem
@@ -562,14 +584,21 @@ class HipEngine:
         bnp = "image_encoder.stem.1"
         call("vqa_bn_bwd_finalize", ptr(slab), nb, 64, 1, float(B * H1 * W1), ptr(self.P(bnp + ".weight")), ptr(st["coef"]),
              int(training), ptr(self._gslice(G, bnp + ".weight")), ptr(self._gslice(G, bnp + ".bias")), ptr(bc))
-        dy = torch.empty_like(st["y"])
-        call("vqa_stem_bwd_apply", dt(T), ptr(dxc), ptr(st["idx"]), ptr(st["y"]), ptr(st["coef"]), ptr(bc), ptr(dy), B, H1, W1, 64)
         if self.stem_w2 is not None and K.stem_conv_blocks(B, IH, IW) > 0:
-            K.stem_wgrad(st["images"], dy, self._gslice(G, "image_encoder.stem.0.weight"), B, IH, IW)
+            # dy (B x 112 x 112 x 64) is never written: the weight-gradient kernel rebuilds it row by row
+            dwv = self._gslice(G, "image_encoder.stem.0.weight")
+            if K.PROFILE is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
+            call("vqa_stem_wgrad_fused", ptr(st["images"]), ptr(st["y"]), ptr(dxc), ptr(st["idx"]), ptr(st["coef"]), ptr(bc), ptr(dwv), B, IH, IW)
+            if K.PROFILE is not None:
+                e1.record(); K.PROFILE.append(("stem_wgrad_kernel<true>", 2.0 * B * H1 * W1 * 64 * 147, e0, e1))
         else:
+            dy = torch.empty_like(st["y"])
+            call("vqa_stem_bwd_apply", dt(T), ptr(dxc), ptr(st["idx"]), ptr(st["y"]), ptr(st["coef"]), ptr(bc), ptr(dy), B, H1, W1, 64)
             K.wgrad(dy, st["images"], LY.mat_of(G, self.E["image_encoder.stem.0.weight"]), B * H1 * W1, 64, 147, st["geom"], dtype=T,
                     loader=K.LOADER_STEM)
         seg("image_encoder.stem")
+        self._join_off_path()
         if use_side:
             main.wait_event(ev_tb)
 
@@ -588,10 +617,10 @@ class HipEngine:
         g2 = rec["g2"]; B, Ho, Wo = g2[0], g2[1], g2[2]
         c64_2 = self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1)
         if c64_2:
-            K.wgrad3x3_c64(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo)
+            self._off_path([dy2], lambda: K.wgrad3x3_c64(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo))
             da1, _, _ = K.conv3x3_c64(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
         else:
-            K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T)
+            self._off_path([dy2], lambda: K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T))
             geom_d2 = (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
             da1, _, _ = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1)
         dy1, _ = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["c1"], self.P(p + ".bn1.weight"), Cout, training,
@@ -599,14 +628,14 @@ class HipEngine:
         g1 = rec["g1"]; H, W, stride = g1[1], g1[2], g1[8]
         c64_1 = self._c64_ok(B, H, W, Cin, Cout, 3, stride)
         if c64_1:
-            K.wgrad3x3_c64(rec["x"], dy1, LY.mat_of(G, self.E[p + ".conv1.weight"]), B, H, W)
+            self._off_path([dy1], lambda: K.wgrad3x3_c64(rec["x"], dy1, LY.mat_of(G, self.E[p + ".conv1.weight"]), B, H, W))
         else:
-            K.wgrad(dy1, rec["x"], LY.mat_of(G, self.E[p + ".conv1.weight"]), M, Cout, 9 * Cin, g1, dtype=T)
+            self._off_path([dy1], lambda: K.wgrad(dy1, rec["x"], LY.mat_of(G, self.E[p + ".conv1.weight"]), M, Cout, 9 * Cin, g1, dtype=T))
         Md = B * H * W
         geom_d1 = (B, Ho, Wo, Cout, H, W, 3, 3, stride, 1)
         if has_ds:
             gd = rec["gd"]
-            K.wgrad(dyd, rec["x"], LY.mat_of(G, self.E[p + ".downsample.0.weight"]), M, Cout, Cin, gd, dtype=T)
+            self._off_path([dyd], lambda: K.wgrad(dyd, rec["x"], LY.mat_of(G, self.E[p + ".downsample.0.weight"]), M, Cout, Cin, gd, dtype=T))
             if stride == 2 and H % 2 == 0 and W % 2 == 0:
                 # conv1 (3x3/2) and shortcut (1x1/2) data gradients in ONE launch over parity classes: no redundant taps
                 wt = self._wt.get(p + ".dgrad2")
