@@ -37,7 +37,7 @@ def synth_batch(B, device, seed):
     return images, ids, mask, answers
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=15.0):
     from oracle import vqa_oracle as O
     try:
         avail = len(os.sched_getaffinity(0))
@@ -56,7 +56,7 @@ def cpu_baseline(seconds_budget=25.0):
         tr.step(images, ids, mask, answers)
         n += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 12:
+        if el > seconds_budget or n >= 400:
             break
     return {"value": round(n * B / el, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"{n} fp32 train steps of the CPU oracle at batch {B} (same model/config, dropout on), {el:.1f}s"}
@@ -70,7 +70,8 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="no RCCL/backward overlap")
+    ap.add_argument("--serial", action="store_true", help="single-stream execution (no text-encoder / weight-gradient side streams)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,6 +91,8 @@ def main():
     model = M.VQAModel(compute_dtype=args.dtype, seed=1234).to(dev).train()
     trainer = pkg.trainer.HipTrainer(model, overlap=not args.no_overlap)
     trainer.engine.seed_base += 7919 * rank
+    if args.serial:
+        trainer.engine.two_streams = False
     images, ids, mask, answers = synth_batch(args.batch, dev, 1234 + rank)
 
     def barrier():
@@ -124,21 +127,35 @@ def main():
     roof = None
     if rank == 0:
         K = pkg.kernels
+        # per-kernel durations are only meaningful without kernel concurrency: this one extra step runs single-stream
+        # (the timed region above used the side streams unless --serial); `rocprofv3 ... bench.py --serial` reproduces it.
+        was = trainer.engine.two_streams
+        trainer.engine.two_streams = False
+        trainer.step(images, ids, mask, answers)
         K.PROFILE = []
         trainer.step(images, ids, mask, answers)
         torch.cuda.synchronize()
+        trainer.engine.two_streams = was
         agg = {}
-        for name, flops, e0, e1 in K.PROFILE:
-            a = agg.setdefault(name, [0.0, 0.0, 0])
-            a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += flops; a[2] += 1
+        for name, flops, e0, e1, nbytes in K.PROFILE:
+            a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
+            a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += flops; a[2] += 1; a[3] += nbytes
         K.PROFILE = None
         gemm_time = sum(a[0] for a in agg.values())
-        name, (tt, fl, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        name, (tt, fl, n, nb) = max(agg.items(), key=lambda kv: kv[1][0])
         ach = fl / tt / 1e12
+        traffic = None                      # HBM bytes per launch from rocprofv3 PMC passes (tools/hbm_traffic.py), if recorded
+        tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and args.batch == 512 and args.dtype == "bf16":
+            for kname, v in json.load(open(tpath))["kernels"].items():
+                if name in kname:
+                    traffic = round(v["hbm_bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-                "frac": round(ach / PEAK[args.dtype], 4), "traffic": None, "launches_per_step": n,
+                "frac": round(ach / PEAK[args.dtype], 4), "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE)",
+                "algorithmic_bytes_per_launch": round(nb / n), "launches_per_step": n,
                 "avg_launch_us": round(tt / n * 1e6, 2), "flop_per_launch": fl / n,
-                "kernel_share_of_step": round(tt / (ms * 1e-3), 3), "all_gemm_share_of_step": round(gemm_time / (ms * 1e-3), 3),
+                "measured": "live HIP events on the launch stream, one single-stream step after the timed region",
+                "kernel_time_ms_per_step": round(tt * 1e3, 3), "all_gemm_time_ms_per_step": round(gemm_time * 1e3, 3),
                 "step_tflops": round(value / world * FLOP_PER_PAIR / 1e12, 2),
                 "per_kernel": {k: {"ms": round(v[0] * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1), "n": v[2]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
     if world > 1:

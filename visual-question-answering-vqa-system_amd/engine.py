@@ -591,7 +591,8 @@ class HipEngine:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
             call("vqa_stem_wgrad_fused", ptr(st["images"]), ptr(st["y"]), ptr(dxc), ptr(st["idx"]), ptr(st["coef"]), ptr(bc), ptr(dwv), B, IH, IW)
             if K.PROFILE is not None:
-                e1.record(); K.PROFILE.append(("stem_wgrad_kernel<true>", 2.0 * B * H1 * W1 * 64 * 147, e0, e1))
+                e1.record(); K.PROFILE.append(("stem_wgrad_kernel<true>", 2.0 * B * H1 * W1 * 64 * 147, e0, e1,
+                                                            B * 3 * IH * IW * 4 + B * H1 * W1 * 64 * 2 + dxc.numel() * 3))
         else:
             dy = torch.empty_like(st["y"])
             call("vqa_stem_bwd_apply", dt(T), ptr(dxc), ptr(st["idx"]), ptr(st["y"]), ptr(st["coef"]), ptr(bc), ptr(dy), B, H1, W1, 64)

@@ -72,7 +72,7 @@ def conv3x3_c64(x, w, B, H, W, *, want_stats=False, addend=None, addmask=None):
     call("vqa_conv3x3_c64", ptr(x), ptr(w), ptr(out), ptr(stats), ptr(addend), ptr(addmask), B, H, W)
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("conv3x3_c64_kernel", 2.0 * B * H * W * 64 * 576, e0, e1))
+        PROFILE.append(("conv3x3_c64_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
     return out, stats, nb
 
 
@@ -83,7 +83,7 @@ def wgrad3x3_c64(x, dy, dw, B, H, W):
     call("vqa_wgrad3x3_c64", ptr(x), ptr(dy), ptr(dw), B, H, W)
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("wgrad3x3_c64_kernel", 2.0 * B * H * W * 64 * 576, e0, e1))
+        PROFILE.append(("wgrad3x3_c64_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
 
 
 def dgrad_s2(dy, dyd, wt, B, H, W, C, Ho, Wo, N, R, pad, *, dtype):
@@ -96,7 +96,8 @@ def dgrad_s2(dy, dyd, wt, B, H, W, C, Ho, Wo, N, R, pad, *, dtype):
     if PROFILE is not None:
         e1.record()
         flops = 2.0 * B * H * W * C * N * (R * R + (1 if dyd is not None else 0))
-        PROFILE.append((f"igemm_kernel<{_tname(dtype)}, 128, {64 if N <= 64 else 128}, 2>", flops, e0, e1))
+        PROFILE.append((f"igemm_kernel<{_tname(dtype)}, 128, {64 if N <= 64 else 128}, 2>", flops, e0, e1,
+                        (B * H * W * C * (2 if dyd is not None else 1) + B * Ho * Wo * N) * 2))
     return out
 
 
@@ -109,7 +110,7 @@ def stem_wgrad(img, dy, dw, B, H, W):
     call("vqa_stem_wgrad", ptr(img), ptr(dy), ptr(dw), B, H, W)
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("stem_wgrad_kernel", 2.0 * B * Ho * Wo * 64 * 147, e0, e1))
+        PROFILE.append(("stem_wgrad_kernel<false>", 2.0 * B * Ho * Wo * 64 * 147, e0, e1, B * 3 * H * W * 4 + B * Ho * Wo * 64 * 2))
 
 
 def stem_conv_blocks(B, H, W) -> int:
@@ -128,7 +129,7 @@ def stem_conv(img, wstem, B, H, W, want_stats):
     call("vqa_stem_conv", ptr(img), ptr(wstem), ptr(y), ptr(stats), B, H, W)
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("stem_conv_kernel", 2.0 * B * Ho * Wo * 64 * 147, e0, e1))
+        PROFILE.append(("stem_conv_kernel", 2.0 * B * Ho * Wo * 64 * 147, e0, e1, B * 3 * H * W * 4 + B * Ho * Wo * 64 * 2))
     return y, stats, nb
 
 
@@ -153,7 +154,9 @@ def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=
         bm, bn = _tile(M, N, loader)
         kreal = 147 if loader == LOADER_STEM else Kw
         flops = 2.0 * B * H * W * C * R * S * N if transposed else 2.0 * M * N * kreal
-        PROFILE.append((f"igemm_kernel<{_tname(dtype)}, {bm}, {bn}, {loader}>", flops, e0, e1))
+        es = 2 if dtype == torch.bfloat16 else 4
+        nbytes = (B * H * W * C * (4 if loader == LOADER_STEM else es)) + (M * N + N * Kw) * es
+        PROFILE.append((f"igemm_kernel<{_tname(dtype)}, {bm}, {bn}, {loader}>", flops, e0, e1, nbytes))
     return out, stats, mt
 
 
@@ -168,7 +171,9 @@ def wgrad(dy, x, dw, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC):
         e1.record()
         big = N >= 128 and ((C % 128 == 0) if R * S > 1 else (Kw >= 128)) and loader == LOADER_NHWC
         t = 128 if big else 64
-        PROFILE.append((f"wgrad_kernel<{_tname(dtype)}, {t}, {t}, {loader}>", 2.0 * M * N * Kw, e0, e1))
+        es = 2 if dtype == torch.bfloat16 else 4
+        PROFILE.append((f"wgrad_kernel<{_tname(dtype)}, {t}, {t}, {loader}>", 2.0 * M * N * Kw, e0, e1,
+                        (M * N + B * H * W * C) * es + N * Kw * 4))
 
 
 def linear_geom(M, K):
