@@ -83,15 +83,20 @@ __device__ __forceinline__ Vec16<T> load_a_stem(const float* img, const RowInfo&
   return v;
 }
 
+// LDS tiles are unpadded 128-byte rows; the 16-byte chunk c of row r lives at chunk position c ^ (r & 7), which makes both
+// the ds_write_b128 staging stores and the ds_read_b128 / ds_read_b32 fragment reads bank-conflict free (the former
+// +16 B row padding was 2-way conflicted on every fragment read).
 template <typename T, int BM, int BN> struct IGemmCfg {
-  static constexpr int LD = GT<T>::BK + GT<T>::VEC;
-  static constexpr int SMEM = 2 * (BM + BN) * LD * (int)sizeof(T);
+  static constexpr int LD = GT<T>::BK;
+  static constexpr int TILES = 2 * (BM + BN) * LD * (int)sizeof(T);
+  static constexpr int CST = BM * (BN + GT<T>::VEC) * (int)sizeof(T);
+  static constexpr int SMEM = (TILES > CST ? TILES : CST) + 4096;      // + BN-statistics scratch at the end
 };
 
 template <typename T, int BM, int BN, int LOADER>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   using G = GT<T>;
-  constexpr int VEC = G::VEC, BK = G::BK, LD = BK + VEC;
+  constexpr int VEC = G::VEC, BK = G::BK, LD = BK;
   constexpr int WN = BN / 64, WM = 4 / WN, TM = BM / WM, MT = TM / 16, NT = 4;
   constexpr int AV = BM / 32, BV = BN / 32;
   constexpr int SMEM = IGemmCfg<T, BM, BN>::SMEM;
@@ -209,11 +214,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AV; ++i)
-      *reinterpret_cast<u32x4*>(&As[(buf * BM + rbase + 32 * i) * LD + vec * VEC]) = ra[i].raw;
+    for (int i = 0; i < AV; ++i)      // (rbase + 32 i) & 7 == rbase & 7
+      *reinterpret_cast<u32x4*>(&As[(buf * BM + rbase + 32 * i) * LD + ((vec ^ (rbase & 7)) * VEC)]) = ra[i].raw;
 #pragma unroll
     for (int i = 0; i < BV; ++i)
-      *reinterpret_cast<u32x4*>(&Bs[(buf * BN + rbase + 32 * i) * LD + vec * VEC]) = rb[i].raw;
+      *reinterpret_cast<u32x4*>(&Bs[(buf * BN + rbase + 32 * i) * LD + ((vec ^ (rbase & 7)) * VEC)]) = rb[i].raw;
   };
   auto compute = [&](int buf) {
     const T* Ab = As + (buf * BM + wm * TM + (lane & 15)) * LD;
@@ -223,9 +228,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
       if constexpr (sizeof(T) == 2) {
         bf16x8 af[MT], bfv[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 16 * LD + kk * 32 + (lane >> 4) * 8);
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 16 * LD + (((kk * 4 + (lane >> 4)) ^ (lane & 7)) * 8));
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bfv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 16 * LD + kk * 32 + (lane >> 4) * 8);
+        for (int j = 0; j < NT; ++j) bfv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 16 * LD + (((kk * 4 + (lane >> 4)) ^ (lane & 7)) * 8));
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -234,9 +239,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
       } else {
         float af[MT], bfv[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = Ab[i * 16 * LD + kk * 4 + (lane >> 4)];
+        for (int i = 0; i < MT; ++i) af[i] = Ab[i * 16 * LD + ((kk ^ (lane & 7)) * 4) + (lane >> 4)];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bfv[j] = Bb[j * 16 * LD + kk * 4 + (lane >> 4)];
+        for (int j = 0; j < NT; ++j) bfv[j] = Bb[j * 16 * LD + ((kk ^ (lane & 7)) * 4) + (lane >> 4)];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
