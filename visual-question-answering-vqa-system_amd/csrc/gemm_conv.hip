@@ -376,11 +376,23 @@ struct WgradParams {
   unsigned long long mul_howo, mul_wo;       // ceil(2^40 / d): exact m / d for m*d < 2^40
 };
 
+// Offset of element (k, col) in a k-major wgrad tile of WIDTH columns.  bf16: unpadded rows, the 32-byte chunk index is XORed
+// with a function of k chosen so that the 8 rows one half-wave touches in a ds_read_b64_tr_b16 ({0..3, 8..11} + 16n) land in
+// 8 different 32-byte bank slots (the padded layout was 2-way conflicted).  fp32 keeps the padded layout (plain ds_read_b32).
+template <typename T, int WIDTH> __device__ __forceinline__ int kmaj_off(int k, int col) {
+  if constexpr (sizeof(T) == 2) {
+    const int h = (WIDTH == 128) ? ((k & 3) | (((k >> 3) & 1) << 2)) : (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
+    return k * WIDTH + ((((col >> 4) ^ h) << 4) | (col & 15));
+  } else {
+    return k * (WIDTH + 4) + col;
+  }
+}
+
 template <typename T, int BMW, int BNW, int LOADER>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   using G = GT<T>;
   constexpr int VEC = G::VEC, BKM = G::BKM;
-  constexpr int LDY = BMW + VEC, LDX = BNW + VEC;
+  constexpr int LDY = (sizeof(T) == 2) ? BMW : BMW + VEC, LDX = (sizeof(T) == 2) ? BNW : BNW + VEC;
   constexpr int TMW = BMW / 2, TNW = BNW / 2, MT = TMW / 16, NT = TNW / 16;
   constexpr int VRY = BMW / VEC, VRX = BNW / VEC;
   constexpr int YV = BKM * VRY / 256, XV = BKM * VRX / 256;
@@ -449,11 +461,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int i = 0; i < YV; ++i) {
       const int idx = tid + 256 * i, row = idx / VRY, v = idx - row * VRY;
-      *reinterpret_cast<u32x4*>(&Ys[(buf * BKM + row) * LDY + v * VEC]) = ry[i].raw;
+      *reinterpret_cast<u32x4*>(&Ys[buf * BKM * LDY + kmaj_off<T, BMW>(row, v * VEC)]) = ry[i].raw;
     }
 #pragma unroll
     for (int i = 0; i < XV; ++i)
-      *reinterpret_cast<u32x4*>(&Xs[(buf * BKM + xrow) * LDX + (xv0 + XT * i) * VEC]) = rx[i].raw;
+      *reinterpret_cast<u32x4*>(&Xs[buf * BKM * LDX + kmaj_off<T, BNW>(xrow, (xv0 + XT * i) * VEC)]) = rx[i].raw;
   };
   auto compute = [&](int buf) {
     const int g = lane >> 4, li = lane & 15;
@@ -463,21 +475,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       const int q = li >> 2, pp = li & 3;
 #pragma unroll
       for (int ks = 0; ks < BKM / 32; ++ks) {
-        const T* yb = Ys + (buf * BKM + ks * 32 + 8 * g + q) * LDY + wm * TMW + 4 * pp;
-        const T* xb = Xs + (buf * BKM + ks * 32 + 8 * g + q) * LDX + wn * TNW + 4 * pp;
+        const int k0 = ks * 32 + 8 * g + q;                                  // rows k0 (lo) and k0 + 4 (hi): same swizzle term
+        const T* yb = Ys + buf * BKM * LDY;
+        const T* xb = Xs + buf * BKM * LDX;
         typedef __attribute__((ext_vector_type(8))) short i16x8;
         bf16x8 af[MT], bfv[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + i * 16));
-          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + 4 * LDY + i * 16));
+          const int col = wm * TMW + i * 16 + 4 * pp;
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + kmaj_off<T, BMW>(k0, col)));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(yb + kmaj_off<T, BMW>(k0 + 4, col)));
           i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           af[i] = __builtin_bit_cast(bf16x8, t);
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + j * 16));
-          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + 4 * LDX + j * 16));
+          const int col = wn * TNW + j * 16 + 4 * pp;
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + kmaj_off<T, BNW>(k0, col)));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(xb + kmaj_off<T, BNW>(k0 + 4, col)));
           i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           bfv[j] = __builtin_bit_cast(bf16x8, t);
         }
@@ -492,9 +507,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       for (int kk = 0; kk < BKM / 4; ++kk) {
         float af[MT], bfv[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = Ys[(buf * BKM + kk * 4 + g) * LDY + wm * TMW + i * 16 + li];
+        for (int i = 0; i < MT; ++i) af[i] = Ys[buf * BKM * LDY + kmaj_off<T, BMW>(kk * 4 + g, wm * TMW + i * 16 + li)];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bfv[j] = Xs[(buf * BKM + kk * 4 + g) * LDX + wn * TNW + j * 16 + li];
+        for (int j = 0; j < NT; ++j) bfv[j] = Xs[buf * BKM * LDX + kmaj_off<T, BNW>(kk * 4 + g, wn * TNW + j * 16 + li)];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -582,7 +597,7 @@ static int igemm_dispatch(const IGemmParams& p, int loader, hipStream_t st) {
 template <typename T, int BMW, int BNW, int LOADER>
 static int launch_wgrad(const WgradParams& p, int nsplit, hipStream_t st) {
   constexpr int VEC = GT<T>::VEC;
-  constexpr int SMEM = 2 * GT<T>::BKM * (BMW + VEC + BNW + VEC) * (int)sizeof(T);
+  constexpr int SMEM = 2 * GT<T>::BKM * (BMW + BNW + (sizeof(T) == 2 ? 0 : 2 * VEC)) * (int)sizeof(T);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BMW, BNW, LOADER>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -709,8 +724,11 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
   const int bmw = big ? 128 : 64, bnw = big ? 128 : 64;
   if (loader == LOADER_NHWC && R * S > 1 && (C % bnw)) return VQA_EARG;
   const long tiles = (long)((N + bmw - 1) / bmw) * ((Kw + bnw - 1) / bnw);
-  static const long target = getenv("VQA_WGRAD_TARGET") ? atol(getenv("VQA_WGRAD_TARGET")) : 2048;
-  p.dbg_noatomic = getenv("VQA_WGRAD_NOATOMIC") ? 1 : 0;
+  // split-K factor: more workgroups hide latency, but every split adds a tile's worth of fp32 atomics (measured: ~1000
+  // workgroups is the sweet spot for the 128x128 tile, ~2000 for the 64x64 tile)
+  static const long target_env = getenv("VQA_WGRAD_TARGET") ? atol(getenv("VQA_WGRAD_TARGET")) : 0;
+  const long target = target_env ? target_env : (big ? 1024 : 2048);
+  p.dbg_noatomic = 0;
   long nsplit = (target + tiles - 1) / tiles;                 // aim for ~target workgroups
   long maxsplit = (M + 255) / 256;                           // at least 256 rows per split
   if (nsplit > maxsplit) nsplit = maxsplit;
