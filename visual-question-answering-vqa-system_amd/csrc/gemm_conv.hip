@@ -154,11 +154,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a2 ? p.a2 : p.a), 0, (int)p.a2_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  // LDS-DMA staging (buffer_load ... lds): a wave-instruction writes 64 x 16 B linearly = 8 consecutive 128-byte tile rows,
+  // so the XOR swizzle is applied on the SOURCE side: the lane sitting at chunk position `vec` of row r fetches chunk
+  // lvec = vec ^ (r & 7).  No staging VGPRs, no ds_write; out-of-range offsets land as zeros.
+  constexpr bool DMA = (LOADER != LOADER_STEM);
+  const int lvec = DMA ? (vec ^ (rbase & 7)) : vec;
   int aoff[AV], boff[BV];
 #pragma unroll
   for (int i = 0; i < BV; ++i) {
     const int n = n0 + rbase + 32 * i;
-    boff[i] = (n < p.N) ? (n * p.Kw + vec * VEC) * (int)sizeof(T) : OOB;
+    boff[i] = (n < p.N) ? (n * p.Kw + lvec * VEC) * (int)sizeof(T) : OOB;
   }
   auto set_tap = [&](int r, int s) {          // r,s: filter tap (NHWC) or (dh,dw) source offsets (DGRAD2)
 #pragma unroll
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         else { ih = th / p.stride; iw = tw / p.stride; ok = ok && (ih * p.stride == th) && (iw * p.stride == tw); }
       }
       ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      aoff[i] = ok ? ((ri[i].pix + ih * p.W + iw) * p.C + vec * VEC) * (int)sizeof(T) : OOB;
+      aoff[i] = ok ? ((ri[i].pix + ih * p.W + iw) * p.C + lvec * VEC) * (int)sizeof(T) : OOB;
     }
   };
   int cc = 0, tap = 0, tr_ = 0, ts_ = 0;
@@ -193,18 +198,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
       return;
     }
     const int kbyte = cc * BK * (int)sizeof(T);
-    const bool cok = (taps > 1 || LOADER == LOADER_DGRAD2) ? true : (cc * BK + vec * VEC) < p.C;      // Linear K tail
+    const bool cok = (taps > 1 || LOADER == LOADER_DGRAD2) ? true : (cc * BK + lvec * VEC) < p.C;      // Linear K tail
     const bool second = (LOADER == LOADER_DGRAD2) && p.tap_src[cls][tap];
+    const int kw = (LOADER == LOADER_DGRAD2) ? p.tap_koff[cls][tap] + cc * BK : kt * BK;
+    const bool kok = (kw + lvec * VEC) < p.Kw;
+#if defined(__HIP_DEVICE_COMPILE__)     // device pass only: the host pass cannot form LDS (address_space 3) pointers
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    char* abase = smem + ((size_t)((kt & 1) * BM + wave * 8) * LD) * sizeof(T);
+    char* bbase = smem + ((size_t)(2 * BM + (kt & 1) * BN + wave * 8) * LD) * sizeof(T);
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int vo = cok ? aoff[i] + kbyte : OOB;
-      ra[i].raw = second ? __builtin_amdgcn_raw_buffer_load_b128(rsA2, vo, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0);
+      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(abase + i * 32 * LD * (int)sizeof(T)), 16, vo, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(abase + i * 32 * LD * (int)sizeof(T)), 16, vo, 0, 0, 0);
     }
-    const int kw = (LOADER == LOADER_DGRAD2) ? p.tap_koff[cls][tap] + cc * BK : kt * BK;
-    const bool kok = (kw + vec * VEC) < p.Kw;
 #pragma unroll
     for (int i = 0; i < BV; ++i)
-      rb[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsW, kok ? boff[i] + kw * (int)sizeof(T) : OOB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(bbase + i * 32 * LD * (int)sizeof(T)), 16,
+                                               kok ? boff[i] + kw * (int)sizeof(T) : OOB, 0, 0, 0);
+#else
+    (void)kbyte; (void)cok; (void)second; (void)kw; (void)kok;
+#endif
     // advance the (tap, channel-chunk) cursor for the next call
     if (++cc == cpb) {
       cc = 0; ++tap;
@@ -251,12 +265,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     }
   };
 
-  if (nk > 0) { gload(0); sstore(0); }
-  __syncthreads();
+  if (nk > 0) { gload(0); if (!DMA) sstore(0); }
+  __syncthreads();                       // (with LDS-DMA in flight the barrier's fence waits vmcnt(0): tile 0 has landed)
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload(kt + 1);
+    if (kt + 1 < nk) gload(kt + 1);      // DMA: straight into the other LDS buffer, all waves left it at the last barrier
     compute(kt & 1);
-    if (kt + 1 < nk) sstore((kt + 1) & 1);
+    if (!DMA && kt + 1 < nk) sstore((kt + 1) & 1);
     __syncthreads();
   }
 
