@@ -68,11 +68,13 @@ int vqa_bn_apply(int dtype, const void* y, const float* coef, const void* res, c
                  long long numel, int C, int relu, hipStream_t stream);
 int vqa_bn_bwd_blocks(long long rows);
 int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const void* y, const float* coef, const void* y2,
-                      const float* coef2, float* slab /* [blocks][3][C] */, long long rows, int C, hipStream_t stream);
+                      const float* coef2, float* slab /* [blocks][3][C] */, long long rows, int C, int self_mask /* mask = relu(bn(y))>0 from y */,
+                      hipStream_t stream);
 int vqa_bn_bwd_finalize(const float* slab, int nblk, int C, int which, double count, const float* gamma, const float* coef,
                         int training, float* dgamma, float* dbeta, float* bcoef /* 3*C */, hipStream_t stream);
 int vqa_bn_bwd_apply(int dtype, const void* dout, const void* outact, const void* y, const float* bcoef, void* dy,
-                     const void* y2, const float* bcoef2, void* dy2, long long numel, int C, hipStream_t stream);
+                     const void* y2, const float* bcoef2, void* dy2, long long numel, int C, const float* mask_coef /* or NULL */,
+                     hipStream_t stream);
 
 /* ---- stem tail: BN + ReLU + MaxPool2d(3,2,1) fused (models/cnn_backbone.py:351-353) ----------------------------- */
 int vqa_stem_pool_fwd(int dtype, const void* y, const float* coef, void* out, uint8_t* idx, int B, int H, int W, int C, hipStream_t stream);

@@ -35,9 +35,9 @@ SIGNATURES = {
     "vqa_bn_eval_coef": [I, P, P, P, P, F, P, P],
     "vqa_bn_apply": [I, P, P, P, P, P, LL, I, I, P],
     "vqa_bn_bwd_blocks": [LL],
-    "vqa_bn_bwd_reduce": [I, P, P, P, P, P, P, P, LL, I, P],
+    "vqa_bn_bwd_reduce": [I, P, P, P, P, P, P, P, LL, I, I, P],
     "vqa_bn_bwd_finalize": [P, I, I, I, D, P, P, I, P, P, P, P],
-    "vqa_bn_bwd_apply": [I, P, P, P, P, P, P, P, P, LL, I, P],
+    "vqa_bn_bwd_apply": [I, P, P, P, P, P, P, P, P, LL, I, P, P],
     "vqa_stem_pool_fwd": [I, P, P, P, P, I, I, I, I, P],
     "vqa_stem_bwd_reduce": [I, P, P, P, P, P, I, I, I, I, P],
     "vqa_stem_bwd_apply": [I, P, P, P, P, P, P, I, I, I, I, P],

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ outact, const T* __restrict__ y,
                                                             const float* __restrict__ coef, const T* __restrict__ y2,
-                                                            const float* __restrict__ coef2, float* __restrict__ slab, size_t rows, int C) {
+                                                            const float* __restrict__ coef2, float* __restrict__ slab, size_t rows, int C,
+                                                            int self_mask) {
   constexpr int VEC = Vec16<T>::N;
   const int cv = C / VEC;                 // vectors per row
   const int lanes_r = 256 / cv;           // rows processed concurrently by the block (C <= 256*VEC)
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       for (int j = 0; j < VEC; ++j) {
         float g = d.get(j);
         if (outact && !(o.get(j) > 0.f)) g = 0.f;
+        if (self_mask && !(yy.get(j) * coef[c0 + j] + coef[C + c0 + j] > 0.f)) g = 0.f;   // relu(bn(y)) > 0 recomputed from y
         sg[j] += g;
         sx[j] += g * (yy.get(j) - coef[2 * C + c0 + j]) * coef[3 * C + c0 + j];
         if (y2) sx2[j] += g * (y2v.get(j) - coef2[2 * C + c0 + j]) * coef2[3 * C + c0 + j];
@@ -163,34 +165,39 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 }
 
 // dy = A*g + B*y + C ; optional second output dy2 = A2*g + B2*y2 + C2 ; optional gout = g (T) for the identity path
-template <typename T>
+// SELF: the ReLU mask is relu(bn(y)) > 0 recomputed from y with mcoef (scale, shift); otherwise outact > 0 (or none).
+// DUAL: second BN (1x1 shortcut) sharing g.  Specialised so unused coefficient sets cost no registers.
+template <typename T, bool SELF, bool DUAL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ outact, const T* __restrict__ y,
                                     const float* __restrict__ bc, T* __restrict__ dy, const T* __restrict__ y2,
-                                    const float* __restrict__ bc2, T* __restrict__ dy2, size_t rows, int C) {
+                                    const float* __restrict__ bc2, T* __restrict__ dy2, size_t rows, int C,
+                                    const float* __restrict__ mcoef) {
   constexpr int VEC = Vec16<T>::N;
   const int cv = C / VEC, lanes_r = 256 / cv;
   const int c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
-  float a[VEC], b[VEC], c[VEC], a2[VEC], b2[VEC], c2[VEC];
+  float a[VEC], b[VEC], c[VEC], a2[DUAL ? VEC : 1], b2[DUAL ? VEC : 1], c2[DUAL ? VEC : 1], ms[SELF ? VEC : 1], mh[SELF ? VEC : 1];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     a[j] = bc[c0 + j]; b[j] = bc[C + c0 + j]; c[j] = bc[2 * C + c0 + j];
-    a2[j] = y2 ? bc2[c0 + j] : 0.f; b2[j] = y2 ? bc2[C + c0 + j] : 0.f; c2[j] = y2 ? bc2[2 * C + c0 + j] : 0.f;
+    if (DUAL) { a2[j] = bc2[c0 + j]; b2[j] = bc2[C + c0 + j]; c2[j] = bc2[2 * C + c0 + j]; }
+    if (SELF) { ms[j] = mcoef[c0 + j]; mh[j] = mcoef[C + c0 + j]; }
   }
 #pragma unroll 2
   for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
     const size_t off = r * C + c0;
     Vec16<T> d = ldg16(dout + off), yy = ldg16(y + off), o, y2v, rr, r2;
-    if (outact) o = ldg16(outact + off);
-    if (y2) y2v = ldg16(y2 + off);
+    if (!SELF && outact) o = ldg16(outact + off);
+    if (DUAL) y2v = ldg16(y2 + off);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float g = d.get(j);
-      if (outact && !(o.get(j) > 0.f)) g = 0.f;
+      if (SELF) { if (!(yy.get(j) * ms[j] + mh[j] > 0.f)) g = 0.f; }
+      else if (outact && !(o.get(j) > 0.f)) g = 0.f;
       rr.set(j, a[j] * g + b[j] * yy.get(j) + c[j]);
-      if (y2) r2.set(j, a2[j] * g + b2[j] * y2v.get(j) + c2[j]);
+      if (DUAL) r2.set(j, a2[j] * g + b2[j] * y2v.get(j) + c2[j]);
     }
     stg16(dy + off, rr);
-    if (y2) stg16(dy2 + off, r2);
+    if (DUAL) stg16(dy2 + off, r2);
   }
 }
 
@@ -589,13 +596,13 @@ int vqa_bn_apply(int dtype, const void* y, const float* coef, const void* res, c
 int vqa_bn_bwd_blocks(long long rows) { long long g = (rows + 63) / 64; return (int)(g > 768 ? 768 : (g < 1 ? 1 : g)); }
 // slab: [vqa_bn_bwd_blocks(rows)][3][C] floats
 int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const void* y, const float* coef, const void* y2, const float* coef2,
-                      float* slab, long long rows, int C, hipStream_t st) {
+                      float* slab, long long rows, int C, int self_mask, hipStream_t st) {
   const int VEC = dtype ? 8 : 4;
   if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
   const int nb = vqa_bn_bwd_blocks(rows);
   const size_t shm = (size_t)3 * 256 * VEC * 4;
-  DT(hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb), dim3(256), shm, st, (const float*)dout, (const float*)outact, (const float*)y, coef, (const float*)y2, coef2, slab, (size_t)rows, C),
-     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)outact, (const bf16_t*)y, coef, (const bf16_t*)y2, coef2, slab, (size_t)rows, C));
+  DT(hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb), dim3(256), shm, st, (const float*)dout, (const float*)outact, (const float*)y, coef, (const float*)y2, coef2, slab, (size_t)rows, C, self_mask),
+     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)outact, (const bf16_t*)y, coef, (const bf16_t*)y2, coef2, slab, (size_t)rows, C, self_mask));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_bn_bwd_finalize(const float* slab, int nblk, int C, int which, double count, const float* gamma, const float* coef, int training,
@@ -604,13 +611,17 @@ int vqa_bn_bwd_finalize(const float* slab, int nblk, int C, int which, double co
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_bn_bwd_apply(int dtype, const void* dout, const void* outact, const void* y, const float* bc, void* dy,
-                     const void* y2, const float* bc2, void* dy2, long long numel, int C, hipStream_t st) {
+                     const void* y2, const float* bc2, void* dy2, long long numel, int C, const float* mask_coef, hipStream_t st) {
   const int VEC = dtype ? 8 : 4;
   if (C % VEC || numel % C || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
   const size_t rows = (size_t)numel / C;
   const int grid = row_grid(rows, 256 / (C / VEC));
-  DT(hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)outact, (const float*)y, bc, (float*)dy, (const float*)y2, bc2, (float*)dy2, rows, C),
-     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (const bf16_t*)y, bc, (bf16_t*)dy, (const bf16_t*)y2, bc2, (bf16_t*)dy2, rows, C));
+#define BWD_APPLY(TT, S, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, S, D>), dim3(grid), dim3(256), 0, st, (const TT*)dout, (const TT*)outact, \
+    (const TT*)y, bc, (TT*)dy, (const TT*)y2, bc2, (TT*)dy2, rows, C, mask_coef)
+  if (mask_coef && (y2 || outact)) return VQA_EARG;
+  if (dtype) { if (mask_coef) BWD_APPLY(bf16_t, true, false); else if (y2) BWD_APPLY(bf16_t, false, true); else BWD_APPLY(bf16_t, false, false); }
+  else { if (mask_coef) BWD_APPLY(float, true, false); else if (y2) BWD_APPLY(float, false, true); else BWD_APPLY(float, false, false); }
+#undef BWD_APPLY
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 

@@ -10,6 +10,7 @@ RCCL all-reduce while earlier layers are still running.
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -89,7 +90,9 @@ class HipEngine:
         return K.bn_eval_coef(C, self.P(prefix + ".weight"), self.P(prefix + ".bias"),
                               self.buf[prefix + ".running_mean"], self.buf[prefix + ".running_var"])
 
-    def _c64_ok(self, B, H, W, Cin, Cout, R, stride):
+    def _c64_ok(self, B, H, W, Cin, Cout, R, stride, wgrad=False):
+        if not wgrad and not os.environ.get("VQA_C64FWD"):
+            return False          # since the LDS-DMA rewrite the generic implicit GEMM is as fast for forward / data gradient
         return (self.dtype == torch.bfloat16 and Cin == 64 and Cout == 64 and R == 3 and stride == 1 and K.c64_blocks(B, H, W) > 0)
 
     def _wflip(self, name):                  # [Cin][(2-r,2-s)][Cout] operand of the stride-1 data gradient as a plain 3x3 conv
@@ -617,18 +620,20 @@ class HipEngine:
                             dbeta2=gs(p + ".downsample.1.bias") if has_ds else None)
         g2 = rec["g2"]; B, Ho, Wo = g2[0], g2[1], g2[2]
         c64_2 = self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1)
-        if c64_2:
+        if self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1, wgrad=True):
             self._off_path([dy2], lambda: K.wgrad3x3_c64(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo))
-            da1, _, _ = K.conv3x3_c64(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
         else:
             self._off_path([dy2], lambda: K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T))
+        if c64_2:
+            da1, _, _ = K.conv3x3_c64(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
+        else:
             geom_d2 = (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
             da1, _, _ = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1)
-        dy1, _ = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["c1"], self.P(p + ".bn1.weight"), Cout, training,
-                          gs(p + ".bn1.weight"), gs(p + ".bn1.bias"))
+        dy1, _ = K.bn_bwd(da1, None, rec["y1"], rec["c1"], self.P(p + ".bn1.weight"), Cout, training,
+                          gs(p + ".bn1.weight"), gs(p + ".bn1.bias"), self_mask=True)      # a1 > 0 recomputed from y1: a1 is not read
         g1 = rec["g1"]; H, W, stride = g1[1], g1[2], g1[8]
         c64_1 = self._c64_ok(B, H, W, Cin, Cout, 3, stride)
-        if c64_1:
+        if self._c64_ok(B, H, W, Cin, Cout, 3, stride, wgrad=True):
             self._off_path([dy1], lambda: K.wgrad3x3_c64(rec["x"], dy1, LY.mat_of(G, self.E[p + ".conv1.weight"]), B, H, W))
         else:
             self._off_path([dy1], lambda: K.wgrad(dy1, rec["x"], LY.mat_of(G, self.E[p + ".conv1.weight"]), M, Cout, 9 * Cin, g1, dtype=T))

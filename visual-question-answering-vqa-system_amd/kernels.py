@@ -203,13 +203,15 @@ def bn_apply(y, coef, C, relu, res=None, rcoef=None):
     return out
 
 
-def bn_bwd(dout, outact, y, coef, gamma, C, training, dgamma, dbeta, y2=None, coef2=None, gamma2=None, dgamma2=None, dbeta2=None):
+def bn_bwd(dout, outact, y, coef, gamma, C, training, dgamma, dbeta, y2=None, coef2=None, gamma2=None, dgamma2=None, dbeta2=None,
+           self_mask=False):
     """BatchNorm backward for g = dout*(outact>0); optional second BN (1x1 shortcut) sharing g.
-    Returns dy (and dy2)."""
+    self_mask: the ReLU directly follows this BN (no residual), so the mask relu(bn(y)) > 0 is recomputed from y and the
+    activation tensor is not read at all (pass outact=None).  Returns dy (and dy2)."""
     rows = y.numel() // C
     nb = L.count("vqa_bn_bwd_blocks", rows)
     slab = torch.empty((nb, 3, C), device=y.device, dtype=torch.float32)
-    call("vqa_bn_bwd_reduce", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(coef), ptr(y2), ptr(coef2), ptr(slab), rows, C)
+    call("vqa_bn_bwd_reduce", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(coef), ptr(y2), ptr(coef2), ptr(slab), rows, C, int(self_mask))
     bc = torch.empty((3, C), device=y.device, dtype=torch.float32)
     call("vqa_bn_bwd_finalize", ptr(slab), nb, C, 1, float(rows), ptr(gamma), ptr(coef), int(training), ptr(dgamma), ptr(dbeta), ptr(bc))
     dy = torch.empty_like(y)
@@ -218,7 +220,8 @@ def bn_bwd(dout, outact, y, coef, gamma, C, training, dgamma, dbeta, y2=None, co
         bc2 = torch.empty((3, C), device=y.device, dtype=torch.float32)
         call("vqa_bn_bwd_finalize", ptr(slab), nb, C, 2, float(rows), ptr(gamma2), ptr(coef2), int(training), ptr(dgamma2), ptr(dbeta2), ptr(bc2))
         dy2 = torch.empty_like(y2)
-    call("vqa_bn_bwd_apply", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(bc), ptr(dy), ptr(y2), ptr(bc2), ptr(dy2), y.numel(), C)
+    call("vqa_bn_bwd_apply", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(bc), ptr(dy), ptr(y2), ptr(bc2), ptr(dy2), y.numel(), C,
+         ptr(coef) if self_mask else None)
     return dy, dy2
 
 
