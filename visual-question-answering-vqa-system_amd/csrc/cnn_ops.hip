@@ -94,35 +94,35 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 // BatchNorm backward.  g = dout * (out > 0) (relu) or dout.  Partial sums per block -> slab [blocks][3][C]:
 //   0: sum g   1: sum g*xhat(y)   2: sum g*xhat(y2) (second BN sharing g: the 1x1 shortcut)
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool SELF, bool DUAL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ outact, const T* __restrict__ y,
                                                             const float* __restrict__ coef, const T* __restrict__ y2,
-                                                            const float* __restrict__ coef2, float* __restrict__ slab, size_t rows, int C,
-                                                            int self_mask) {
+                                                            const float* __restrict__ coef2, float* __restrict__ slab, size_t rows, int C) {
   constexpr int VEC = Vec16<T>::N;
   const int cv = C / VEC;                 // vectors per row
   const int lanes_r = 256 / cv;           // rows processed concurrently by the block (C <= 256*VEC)
-  const int myv = threadIdx.x % cv, myr = threadIdx.x / cv;
-  float sg[VEC], sx[VEC], sx2[VEC];
+  const int myv = threadIdx.x % cv, myr = threadIdx.x / cv, c0 = myv * VEC;
+  float sg[VEC], sx[VEC], sx2[DUAL ? VEC : 1], mean[VEC], inv[VEC], ms[SELF ? VEC : 1], mh[SELF ? VEC : 1], mean2[DUAL ? VEC : 1], inv2[DUAL ? VEC : 1];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) sg[j] = sx[j] = sx2[j] = 0.f;
-  if (myr < lanes_r) {
-    const int c0 = myv * VEC;
+  for (int j = 0; j < VEC; ++j) {
+    sg[j] = sx[j] = 0.f; mean[j] = coef[2 * C + c0 + j]; inv[j] = coef[3 * C + c0 + j];
+    if (DUAL) { sx2[j] = 0.f; mean2[j] = coef2[2 * C + c0 + j]; inv2[j] = coef2[3 * C + c0 + j]; }
+    if (SELF) { ms[j] = coef[c0 + j]; mh[j] = coef[C + c0 + j]; }
+  }
 #pragma unroll 2
-    for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
-      const size_t off = r * C + c0;
-      Vec16<T> d = ldg16(dout + off), yy = ldg16(y + off), o, y2v;
-      if (outact) o = ldg16(outact + off);
-      if (y2) y2v = ldg16(y2 + off);
+  for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
+    const size_t off = r * C + c0;
+    Vec16<T> d = ldg16(dout + off), yy = ldg16(y + off), o, y2v;
+    if (!SELF && outact) o = ldg16(outact + off);
+    if (DUAL) y2v = ldg16(y2 + off);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        float g = d.get(j);
-        if (outact && !(o.get(j) > 0.f)) g = 0.f;
-        if (self_mask && !(yy.get(j) * coef[c0 + j] + coef[C + c0 + j] > 0.f)) g = 0.f;   // relu(bn(y)) > 0 recomputed from y
-        sg[j] += g;
-        sx[j] += g * (yy.get(j) - coef[2 * C + c0 + j]) * coef[3 * C + c0 + j];
-        if (y2) sx2[j] += g * (y2v.get(j) - coef2[2 * C + c0 + j]) * coef2[3 * C + c0 + j];
-      }
+    for (int j = 0; j < VEC; ++j) {
+      float g = d.get(j);
+      if (SELF) { if (!(yy.get(j) * ms[j] + mh[j] > 0.f)) g = 0.f; }       // relu(bn(y)) > 0 recomputed from y
+      else if (outact && !(o.get(j) > 0.f)) g = 0.f;
+      sg[j] += g;
+      sx[j] += g * (yy.get(j) - mean[j]) * inv[j];
+      if (DUAL) sx2[j] += g * (y2v.get(j) - mean2[j]) * inv2[j];
     }
   }
   extern __shared__ float shm[];          // [3][256][VEC]
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   for (int j = 0; j < VEC; ++j) {
     shm[(0 * 256 + threadIdx.x) * VEC + j] = sg[j];
     shm[(1 * 256 + threadIdx.x) * VEC + j] = sx[j];
-    shm[(2 * 256 + threadIdx.x) * VEC + j] = sx2[j];
+    shm[(2 * 256 + threadIdx.x) * VEC + j] = DUAL ? sx2[j] : 0.f;
   }
   __syncthreads();
   for (int o = threadIdx.x; o < 3 * C; o += 256) {
@@ -601,8 +601,12 @@ int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const voi
   if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
   const int nb = vqa_bn_bwd_blocks(rows);
   const size_t shm = (size_t)3 * 256 * VEC * 4;
-  DT(hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nb), dim3(256), shm, st, (const float*)dout, (const float*)outact, (const float*)y, coef, (const float*)y2, coef2, slab, (size_t)rows, C, self_mask),
-     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)outact, (const bf16_t*)y, coef, (const bf16_t*)y2, coef2, slab, (size_t)rows, C, self_mask));
+#define BWD_RED(TT, S, D) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, S, D>), dim3(nb), dim3(256), shm, st, (const TT*)dout, (const TT*)outact, \
+    (const TT*)y, coef, (const TT*)y2, coef2, slab, (size_t)rows, C)
+  if (self_mask && (y2 || outact)) return VQA_EARG;
+  if (dtype) { if (self_mask) BWD_RED(bf16_t, true, false); else if (y2) BWD_RED(bf16_t, false, true); else BWD_RED(bf16_t, false, false); }
+  else { if (self_mask) BWD_RED(float, true, false); else if (y2) BWD_RED(float, false, true); else BWD_RED(float, false, false); }
+#undef BWD_RED
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_bn_bwd_finalize(const float* slab, int nblk, int C, int which, double count, const float* gamma, const float* coef, int training,
