@@ -63,27 +63,29 @@ __global__ void bn_eval_coef_kernel(int C, const float* gamma, const float* beta
 
 // out = [relu]( y*scale+shift  [+ res*rscale+rshift | + res] ).  Each thread owns one 16-byte channel vector
 // (coefficients stay in registers) and walks rows; a block covers 256/cv consecutive rows = one contiguous span.
-template <typename T>
+// RES: 0 = none, 1 = + res (identity), 2 = + res*rscale+rshift (the 1x1 shortcut's BatchNorm)
+template <typename T, int RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ coef, const T* __restrict__ res,
                                 const float* __restrict__ rcoef, T* __restrict__ out, size_t rows, int C, int relu) {
   constexpr int VEC = Vec16<T>::N;
   const int cv = C / VEC, lanes_r = 256 / cv;
   const int c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
-  float sc[VEC], sh[VEC], rs[VEC], rh[VEC];
+  float sc[VEC], sh[VEC], rs[RES == 2 ? VEC : 1], rh[RES == 2 ? VEC : 1];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     sc[j] = coef[c0 + j]; sh[j] = coef[C + c0 + j];
-    rs[j] = rcoef ? rcoef[c0 + j] : 1.f; rh[j] = rcoef ? rcoef[C + c0 + j] : 0.f;
+    if (RES == 2) { rs[j] = rcoef[c0 + j]; rh[j] = rcoef[C + c0 + j]; }
   }
 #pragma unroll 2
   for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
     const size_t off = r * C + c0;
     Vec16<T> v = ldg16(y + off), rr, o;
-    if (res) rr = ldg16(res + off);
+    if (RES) rr = ldg16(res + off);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float x = v.get(j) * sc[j] + sh[j];
-      if (res) x += rr.get(j) * rs[j] + rh[j];
+      if (RES == 1) x += rr.get(j);
+      if (RES == 2) x += rr.get(j) * rs[j] + rh[j];
       o.set(j, (relu && x < 0.f) ? 0.f : x);   // NaN-propagating ReLU like torch
     }
     stg16(out + off, o);
@@ -589,8 +591,11 @@ int vqa_bn_apply(int dtype, const void* y, const float* coef, const void* res, c
   if (C % VEC || numel % C || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
   const size_t rows = (size_t)numel / C;
   const int grid = row_grid(rows, 256 / (C / VEC));
-  DT(hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, coef, (const float*)res, rcoef, (float*)out, rows, C, relu),
-     hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)y, coef, (const bf16_t*)res, rcoef, (bf16_t*)out, rows, C, relu));
+#define BN_APPLY(TT, R) hipLaunchKernelGGL((bn_apply_kernel<TT, R>), dim3(grid), dim3(256), 0, st, (const TT*)y, coef, (const TT*)res, rcoef, (TT*)out, rows, C, relu)
+  const int mode = !res ? 0 : (rcoef ? 2 : 1);
+  if (dtype) { if (mode == 0) BN_APPLY(bf16_t, 0); else if (mode == 1) BN_APPLY(bf16_t, 1); else BN_APPLY(bf16_t, 2); }
+  else { if (mode == 0) BN_APPLY(float, 0); else if (mode == 1) BN_APPLY(float, 1); else BN_APPLY(float, 2); }
+#undef BN_APPLY
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_bn_bwd_blocks(long long rows) { long long g = (rows + 63) / 64; return (int)(g > 768 ? 768 : (g < 1 ? 1 : g)); }
