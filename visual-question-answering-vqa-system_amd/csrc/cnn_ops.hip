@@ -212,10 +212,13 @@ __global__ void stem_pool_fwd_kernel(const T* __restrict__ y, const float* __res
   constexpr int VEC = Vec16<T>::N;
   const int cv = C / VEC;
   const size_t total = (size_t)B * Ho * Wo * cv;
+  const int c0 = (int)(threadIdx.x % cv) * VEC;          // fixed per thread: 256 and the grid stride are multiples of cv
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sc[j] = coef[c0 + j]; sh[j] = coef[C + c0 + j]; }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int v = (int)(i % cv); size_t p = i / cv;
+    size_t p = i / cv;
     const int ow = (int)(p % Wo); p /= Wo; const int oh = (int)(p % Ho); const int b = (int)(p / Ho);
-    const int c0 = v * VEC;
     float best[VEC]; int bi[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
@@ -228,7 +231,7 @@ __global__ void stem_pool_fwd_kernel(const T* __restrict__ y, const float* __res
         Vec16<T> yy = ldg16(y + (((size_t)b * H + ih) * W + iw) * C + c0);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          float a = yy.get(j) * coef[c0 + j] + coef[C + c0 + j];
+          float a = yy.get(j) * sc[j] + sh[j];
           a = a < 0.f ? 0.f : a;
           if (a > best[j] || a != a) { best[j] = a; bi[j] = r * 3 + s; }     // first max wins, NaN propagates (ATen max_pool2d)
         }
@@ -249,16 +252,16 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_kernel(const T* __restric
   const int cv = C / VEC, lanes_r = 256 / cv;
   const int myv = threadIdx.x % cv, myr = threadIdx.x / cv, c0 = myv * VEC;
   const size_t rows = (size_t)B * H * W;
-  float sg[VEC], sx[VEC], g[VEC];
+  float sg[VEC], sx[VEC], g[VEC], sc[VEC], sh[VEC], mean[VEC], inv[VEC];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) sg[j] = sx[j] = 0.f;
+  for (int j = 0; j < VEC; ++j) { sg[j] = sx[j] = 0.f; sc[j] = coef[c0 + j]; sh[j] = coef[C + c0 + j]; mean[j] = coef[2 * C + c0 + j]; inv[j] = coef[3 * C + c0 + j]; }
   if (myr < lanes_r)
     for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
       const int w = (int)(r % W); size_t q = r / W; const int h = (int)(q % H); const int b = (int)(q / H);
       Vec16<T> yy = ldg16(y + r * C + c0);
-      stem_route<T>(dpool, idx, yy, coef, b, h, w, c0, C, Ho, Wo, g);
+      stem_route<T>(dpool, idx, yy, sc, sh, b, h, w, c0, C, Ho, Wo, g);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { sg[j] += g[j]; sx[j] += g[j] * (yy.get(j) - coef[2 * C + c0 + j]) * coef[3 * C + c0 + j]; }
+      for (int j = 0; j < VEC; ++j) { sg[j] += g[j]; sx[j] += g[j] * (yy.get(j) - mean[j]) * inv[j]; }
     }
   extern __shared__ float shm[];
 #pragma unroll
@@ -286,7 +289,10 @@ __global__ void stem_bwd_apply_kernel(const T* __restrict__ dpool, const uint8_t
     const int w = (int)(r % W); size_t q = r / W; const int h = (int)(q % H); const int b = (int)(q / H);
     const int c0 = v * VEC;
     Vec16<T> yy = ldg16(y + i * VEC), o;
-    stem_route<T>(dpool, idx, yy, coef, b, h, w, c0, C, Ho, Wo, g);
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sc[j] = coef[c0 + j]; sh[j] = coef[C + c0 + j]; }
+    stem_route<T>(dpool, idx, yy, sc, sh, b, h, w, c0, C, Ho, Wo, g);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o.set(j, bc[c0 + j] * g[j] + bc[C + c0 + j] * yy.get(j) + bc[2 * C + c0 + j]);
     stg16(dy + i * VEC, o);

@@ -161,6 +161,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   for (int i = tid; i < (MP - Wo) * LDA; i += 256) Acol[Wo * LDA + i] = 0;
   for (int i = tid; i < (MP - Wo) * LDD; i += 256) Dy[Wo * LDD + i] = 0;
 
+  // FUSED: this thread always stages channel vector cv = tid & 7 -> its BN / backward coefficients live in registers
+  float f_sc[8], f_sh[8], f_a[8], f_b[8], f_c[8];
+  if (FUSED) {
+    const int c0f = (tid & 7) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f_sc[j] = coef[c0f + j]; f_sh[j] = coef[64 + c0f + j];
+      f_a[j] = bc[c0f + j]; f_b[j] = bc[64 + c0f + j]; f_c[j] = bc[128 + c0f + j];
+    }
+  }
   f32x4 acc[4][3];                                                   // wave owns k2 tiles 3*wave .. 3*wave+2, all 4 n tiles
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -197,10 +207,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         if (FUSED) {
           Vec16<bf16_t> yy; yy.raw = val;
           float g8[8];
-          stem_route<bf16_t>(dpool, idx, yy, coef, b, oh0 + orow, px, cv * 8, 64, Hp, Wp, g8);
+          stem_route<bf16_t>(dpool, idx, yy, f_sc, f_sh, b, oh0 + orow, px, cv * 8, 64, Hp, Wp, g8);
           Vec16<bf16_t> o;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o.set(j, bc[cv * 8 + j] * g8[j] + bc[64 + cv * 8 + j] * yy.get(j) + bc[128 + cv * 8 + j]);
+          for (int j = 0; j < 8; ++j) o.set(j, f_a[j] * g8[j] + f_b[j] * yy.get(j) + f_c[j]);
           val = o.raw;
         }
         uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[px * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned

@@ -5,7 +5,7 @@
 // gradient wrt the (virtual) 112x112 post-ReLU activation, routed through the pool argmax and the ReLU mask
 template <typename T>
 __device__ __forceinline__ void stem_route(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const Vec16<T>& yy,
-                                           const float* __restrict__ coef, int b, int h, int w, int c0, int C, int Ho, int Wo, float* g) {
+                                           const float* sc, const float* sh, int b, int h, int w, int c0, int C, int Ho, int Wo, float* g) {   // sc/sh: this thread's 8 (or 4) scale / shift values, register resident
   constexpr int VEC = Vec16<T>::N;
 #pragma unroll
   for (int j = 0; j < VEC; ++j) g[j] = 0.f;
@@ -34,6 +34,6 @@ __device__ __forceinline__ void stem_route(const T* __restrict__ dpool, const ui
     }
 #pragma unroll
   for (int j = 0; j < VEC; ++j)
-    if (!(yy.get(j) * coef[c0 + j] + coef[C + c0 + j] > 0.f)) g[j] = 0.f;
+    if (!(yy.get(j) * sc[j] + sh[j] > 0.f)) g[j] = 0.f;
 }
 
