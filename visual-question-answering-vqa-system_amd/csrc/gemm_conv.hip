@@ -90,7 +90,7 @@ template <typename T, int BM, int BN> struct IGemmCfg {
   static constexpr int LD = GT<T>::BK;
   static constexpr int TILES = 2 * (BM + BN) * LD * (int)sizeof(T);
   static constexpr int CST = BM * (BN + GT<T>::VEC) * (int)sizeof(T);
-  static constexpr int SMEM = (TILES > CST ? TILES : CST) + 4096;      // + BN-statistics scratch at the end
+  static constexpr int SMEM = (TILES > CST + 4096 ? TILES : CST + 4096);   // BN-statistics scratch sits right after the C staging area
 };
 
 template <typename T, int BM, int BN, int LOADER>
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         }
   }
   // ---- BatchNorm partial statistics (sum, sum of squares per output channel of this M tile) ----
-  float* red = reinterpret_cast<float*>(smem + SMEM - 4096);   // [WM][BN][2]
+  float* red = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN>::CST);   // [WM][BN][2], after the C staging area (tiles are dead by now)
   if (p.stats) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -593,7 +593,7 @@ static int launch_igemm(const IGemmParams& p, hipStream_t st) {
 }
 
 static void igemm_tile(int M, int N, int* bm, int* bn) {
-  if (N <= 64) { *bn = 64; *bm = 128; }
+  if (N <= 64) { *bn = 64; *bm = 128; }      // (256-row tiles were measured slower for the 64-channel layers)
   else { *bn = 128; *bm = 128; }
   long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
   if (tiles < 384) { *bm = 64; *bn = 64; }
