@@ -27,6 +27,6 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -sum(fetch.get(k, [0]))):
     wb = 1024.0 * sum(w) / max(len(w), 1)
     out[k] = {"launches": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
 json.dump({"note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, averaged over all launches of the kernel "
-                   "in `python bench.py --steps 2 --warmup 1` (B=512 bf16)", "kernels": out}, open(sys.argv[3], "w"), indent=1)
+                   "in `python bench.py --steps 2 --warmup 1 --serial` (B=512 bf16)", "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in list(out.items())[:14]:
     print(f"{v['hbm_bytes_per_launch']/1e6:10.1f} MB/launch  (fetch {v['fetch_bytes_per_launch']/1e6:8.1f} write {v['write_bytes_per_launch']/1e6:8.1f})  n={v['launches']:4d}  {k[:70]}")
