@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import importlib
 import os
-from typing import Any, Dict, Optional, Tuple
+from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -28,26 +28,63 @@ class _Node(nn.Module):
     """Anonymous container; the module tree only exists to give parameters their reference names."""
 
 
-class _VQAFunction(torch.autograd.Function):
-    """Whole-model autograd node: forward and backward are explicit kernel sequences (engine.py)."""
+# ----------------------------------------------------------------------------------------------------------------------
+# torch custom ops: the whole HIP forward and backward are registered in the `vqa_hip` namespace
+#   torch.ops.vqa_hip.vqa_forward(images, token_ids, mask, params, handle, training, want_aux) -> logits
+#   torch.ops.vqa_hip.vqa_backward(dlogits, handle, tape_id) -> flat gradient buffer (layout.py slots)
+# with a fake (shape-only) implementation and an autograd formula, so the node is visible to the dispatcher, autograd,
+# and FakeTensor tracing.  `handle` indexes a registry of live models (ops cannot carry Python objects); forward and
+# backward are explicit kernel sequences over the C ABI (engine.py).
+# ----------------------------------------------------------------------------------------------------------------------
+_MODELS: Dict[int, "VQAModel"] = {}
+_NEXT_HANDLE = [1]
 
-    @staticmethod
-    def forward(ctx, model, images, token_ids, maskf, want_aux, *params):
-        logits, aux, tape = model._engine.forward(images, token_ids, maskf, model.training, want_aux, need_tape=True)
-        ctx.model = model
-        ctx.tape = tape
-        model._last_aux = aux          # aux tensors are detached by construction (side channel, not graph outputs)
-        return logits
 
-    @staticmethod
-    def backward(ctx, dlogits):
-        model = ctx.model
-        G = torch.zeros_like(model._flat)
-        model._engine.backward(ctx.tape, dlogits.contiguous(), G, on_segment=model._on_segment)
-        ctx.tape = None
-        lay = model._pkg.layout
-        grads = tuple(lay.view_of(G, e) for e in model._param_entries)
-        return (None, None, None, None, None) + grads
+@torch.library.custom_op("vqa_hip::vqa_forward", mutates_args=(), device_types="cuda")
+def _vqa_forward_op(images: torch.Tensor, token_ids: torch.Tensor, mask: Optional[torch.Tensor], params: List[torch.Tensor],
+                    handle: int, training: bool, want_aux: bool) -> torch.Tensor:
+    model = _MODELS[handle]
+    logits, aux, tape = model._engine.forward(images, token_ids, mask, training, want_aux, need_tape=True)
+    model._last_aux = aux              # aux tensors are detached by construction (side channel, not graph outputs)
+    model._tape_seq += 1
+    model._tapes[model._tape_seq] = tape
+    return logits
+
+
+@_vqa_forward_op.register_fake
+def _(images, token_ids, mask, params, handle, training, want_aux):
+    return images.new_empty((images.shape[0], _MODELS[handle].num_answers), dtype=torch.float32)
+
+
+@torch.library.custom_op("vqa_hip::vqa_backward", mutates_args=(), device_types="cuda")
+def _vqa_backward_op(dlogits: torch.Tensor, handle: int, tape_id: int) -> torch.Tensor:
+    """Returns the FLAT gradient buffer (same layout as the flat parameter buffer); the autograd formula slices it."""
+    model = _MODELS[handle]
+    tape = model._tapes.pop(tape_id)
+    G = torch.zeros_like(model._flat)
+    model._engine.backward(tape, dlogits.contiguous(), G, on_segment=model._on_segment)
+    return G
+
+
+@_vqa_backward_op.register_fake
+def _(dlogits, handle, tape_id):
+    return torch.empty_like(_MODELS[handle]._flat)
+
+
+def _setup_ctx(ctx, inputs, output):
+    handle = inputs[4]
+    ctx.handle = handle
+    ctx.tape_id = _MODELS[handle]._tape_seq
+
+
+def _backward(ctx, dlogits):
+    model = _MODELS[ctx.handle]
+    G = torch.ops.vqa_hip.vqa_backward(dlogits, ctx.handle, ctx.tape_id)
+    lay = model._pkg.layout
+    return None, None, None, [lay.view_of(G, e) for e in model._param_entries], None, None, None
+
+
+torch.library.register_autograd("vqa_hip::vqa_forward", _backward, setup_context=_setup_ctx)
 
 
 class VQAModel(nn.Module):
@@ -96,6 +133,17 @@ class VQAModel(nn.Module):
         self._engine = None
         self._on_segment = None
         self._last_aux = None
+        self._tapes: Dict[int, Any] = {}
+        self._tape_seq = 0
+        self._handle = _NEXT_HANDLE[0]
+        _NEXT_HANDLE[0] += 1
+        _MODELS[self._handle] = self
+
+    def _param_list(self):
+        return [getattr_path(self, e.name) for e in self._param_entries]
+
+    def __del__(self):
+        _MODELS.pop(getattr(self, "_handle", -1), None)
 
     # ---- storage management: parameters are views into one flat buffer; keep that true across .to()/.cuda()
     def _reflatten(self):
@@ -135,9 +183,10 @@ class VQAModel(nn.Module):
         images = images.contiguous().float()
         token_ids = token_ids.contiguous().long()
         maskf = None if attention_mask is None else attention_mask.contiguous().float()
-        params = [getattr_path(self, e.name) for e in self._param_entries]
+        params = self._param_list()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            logits = _VQAFunction.apply(self, images, token_ids, maskf, return_aux, *params)
+            self._tapes.clear()                      # a forward whose backward never ran must not pin its activations
+            logits = torch.ops.vqa_hip.vqa_forward(images, token_ids, maskf, params, self._handle, self.training, return_aux)
             aux, self._last_aux = self._last_aux, None
         else:
             logits, aux, _ = eng.forward(images, token_ids, maskf, self.training, return_aux, need_tape=False)
