@@ -80,3 +80,19 @@ def test_init_distributions_follow_the_reference_recipe():
     assert abs(P["fusion.image_projector.position_embedding"].std().item() - 0.02) < 0.002
     pe = dict(m.named_buffers())["text_encoder.positional_encoding.pe"]
     assert torch.allclose(pe, O.sinusoid_pe(20, 256))
+
+
+def test_torch_custom_ops_are_registered_with_fake_impl():
+    """The HIP forward/backward are torch custom ops (vqa_hip::vqa_forward / vqa_backward); shape inference works on fake tensors."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    M = pkg().load_dropin()
+    m = M.VQAModel(seed=0, num_answers=37)
+    schema = str(torch.ops.vqa_hip.vqa_forward.default._schema)
+    assert "Tensor images" in schema and "Tensor[] params" in schema
+    with FakeTensorMode(allow_non_fake_inputs=True):
+        imgs = torch.empty(3, 3, 224, 224, device="cuda")
+        ids = torch.empty(3, 20, dtype=torch.long, device="cuda")
+        out = torch.ops.vqa_hip.vqa_forward(imgs, ids, None, [], m._handle, False, False)
+        assert tuple(out.shape) == (3, 37) and out.dtype == torch.float32
+        g = torch.ops.vqa_hip.vqa_backward(out, m._handle, 0)
+        assert g.numel() == m._flat.numel()
