@@ -84,7 +84,7 @@ class HipTrainer:
         B, N = logits_f.shape
         dlogits = torch.empty((B, N), device=images.device, dtype=torch.float32)
         call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0)
-        eng.backward(tape, dlogits, self.G, on_segment=self.reducer.on_segment)
+        eng.backward(tape, dlogits, self.G, on_segment=self.reducer.on_segment if self.world > 1 else None)
         gscale = self.reducer.finish()
         call("vqa_sumsq", ptr(self.G), self.G.numel(), ptr(self.sumsq))
         self.t += 1
