@@ -580,9 +580,20 @@ class HipEngine:
         # ---- stem
         st = tape["stem"]
         Bq, IH, IW, _, H1, W1 = st["geom"][:6]
-        nb = K.L.count("vqa_bn_bwd_blocks", B * H1 * W1)
+        # BatchNorm-backward sums of the stem WITHOUT touching the 112x112 tensors: every pooling window routes its gradient to
+        # exactly one position (its argmax), whose post-ReLU value is the pooled output itself, so
+        #   sum g       = sum_windows dpool * [pooled > 0]
+        #   sum g*xhat  = sum_windows dpool * [pooled > 0] * (pooled - beta) / gamma      (pooled = gamma*xhat + beta when > 0)
+        # which is the generic BN-backward reduction with y := pooled, mean := beta, invstd := 1/gamma.
+        pooled = tape["stages"][0]["blocks"][0]["x"]
+        gam, bet = self.P("image_encoder.stem.1.weight"), self.P("image_encoder.stem.1.bias")
+        fcoef = torch.zeros((4, 64), device=dxc.device, dtype=torch.float32)
+        fcoef[2] = bet
+        fcoef[3] = torch.where(gam.abs() > 1e-20, 1.0 / gam, torch.zeros_like(gam))
+        rows_p = pooled.numel() // 64
+        nb = K.L.count("vqa_bn_bwd_blocks", rows_p)
         slab = torch.empty((nb, 3, 64), device=dxc.device, dtype=torch.float32)
-        call("vqa_stem_bwd_reduce", dt(T), ptr(dxc), ptr(st["idx"]), ptr(st["y"]), ptr(st["coef"]), ptr(slab), B, H1, W1, 64)
+        call("vqa_bn_bwd_reduce", dt(T), ptr(dxc), ptr(pooled), ptr(pooled), ptr(fcoef), None, None, ptr(slab), rows_p, 64, 0)
         bc = torch.empty((3, 64), device=dxc.device, dtype=torch.float32)
         bnp = "image_encoder.stem.1"
         call("vqa_bn_bwd_finalize", ptr(slab), nb, 64, 1, float(B * H1 * W1), ptr(self.P(bnp + ".weight")), ptr(st["coef"]),
