@@ -114,6 +114,9 @@ int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* g
 int vqa_attention_fwd(int dtype, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const float* kmask,
                       float* probs, void* ctx, int ldc, int B, int H, int Lq, int Lk, int hd, float p, unsigned long long seed,
                       hipStream_t stream);
+/* bf16 MFMA variant (Lq <= 32, Lk <= 64, hd 32|64): QK^T and PV as v_mfma_f32_32x32x16_bf16 tiles, softmax in registers */
+int vqa_attention_fwd_mfma(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const float* kmask, float* probs,
+                           void* ctx, int ldc, int B, int H, int Lq, int Lk, int hd, float p, unsigned long long seed, hipStream_t stream);
 int vqa_attention_bwd(int dtype, const void* dctx, int ldc, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
                       const float* probs, void* dq, void* dk, void* dv, int lddq, int lddk, int lddv, int B, int H, int Lq, int Lk,
                       int hd, float p, unsigned long long seed, hipStream_t stream);

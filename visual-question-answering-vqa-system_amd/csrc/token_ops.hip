@@ -508,3 +508,132 @@ int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float l
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA attention forward: one wave per (batch, head), Lq <= 32 queries, Lk <= 64 keys, head dim HD in {32, 64}.
+//   S^T (keys x queries) = K . Q^T         v_mfma_f32_32x32x16_bf16, operands loaded straight from global as 16-byte fragments
+//   row softmax over keys: the query sits on the lane, its keys in the 32 accumulator registers of the two key tiles
+//     (+ one exchange with lane^32); probabilities go to the caller through an LDS staging tile (coalesced rows)
+//   ctx = P . V = (P^T)^T . V: the bf16-rounded accumulator registers ARE the A operand of the next MFMA (no lane movement);
+//     V is staged in LDS and read transposed with ds_read_b64_tr_b16 in the matching (permuted) k order.
+// Same masking semantics as the reference: keys with kmask == 0 get -inf before the softmax (an all-masked row is NaN).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                            int ldq, int ldk, int ldv, const float* __restrict__ kmask, float* __restrict__ probs,
+                                                            bf16_t* __restrict__ ctx, int ldc, int BH, int H, int Lq, int Lk, float p, uint64_t seed) {
+  constexpr int LDV = HD;                       // V tile row stride (elements): 64 / 128 bytes, 8-byte aligned for the transposed reads
+  constexpr int LDP = 65;                       // probability staging row stride (floats)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x * 4 + wave;
+  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + wave * (64 * LDV);
+  float* Ps = reinterpret_cast<float*>(smem + 4 * 64 * LDV * 2) + wave * (32 * LDP);
+  if (bh >= BH) return;                         // whole wave exits together; no block-level barrier is used below
+  const int b = bh / H, h = bh - b * H;
+  const int r = lane & 31, hh = lane >> 5;
+  const float inv_scale = 1.0f / sqrtf((float)HD);
+
+  // ---- V -> LDS (rows >= Lk zero), 16-byte vectors
+  for (int i = lane; i < 64 * (HD / 8); i += 64) {
+    const int row = i / (HD / 8), cv = i - row * (HD / 8);
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (row < Lk) val = *reinterpret_cast<const u32x4*>(v + (size_t)(b * Lk + row) * ldv + h * HD + cv * 8);
+    *reinterpret_cast<u32x4*>(&Vs[row * LDV + cv * 8]) = val;
+  }
+  // ---- S^T = K Q^T
+  f32x16 st[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ++ks) {
+    bf16x8 qf = {};
+    if (r < Lq) qf = *reinterpret_cast<const bf16x8*>(q + (size_t)(b * Lq + r) * ldq + h * HD + ks * 16 + 8 * hh);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 kf = {};
+      if (32 * t + r < Lk) kf = *reinterpret_cast<const bf16x8*>(k + (size_t)(b * Lk + 32 * t + r) * ldk + h * HD + ks * 16 + 8 * hh);
+      st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, st[t], 0, 0, 0);
+    }
+  }
+  // ---- scale, mask, softmax over keys (query = lane&31; keys: (e&3) + 8*(e>>2) + 4*hh + 32*t)
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      float s = st[t][e] * inv_scale;
+      if (key >= Lk || (kmask && kmask[b * Lk + key] == 0.f)) s = -INFINITY;
+      st[t][e] = s;
+      m = fmaxf(m, s);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const float ex = expf(st[t][e] - m); st[t][e] = ex; sum += ex; }   // all -inf row -> NaN like torch
+  sum += __shfl_xor(sum, 32, 64);
+  const float rs = 1.0f / sum;
+  const size_t prow = ((size_t)bh * Lq + r) * Lk;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      float pr = st[t][e] * rs;
+      if (sum != sum || m != m) pr = st[t][e] / sum;                       // keep NaN propagation exact (0 * inf etc.)
+      Ps[r * LDP + key] = pr;
+      if (p > 0.f && r < Lq && key < Lk) pr = drop_keep(seed, prow + key, p) ? pr / (1.f - p) : 0.f;
+      st[t][e] = pr;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // wave-private LDS: V tile + probabilities are visible
+  for (int i = lane; i < Lq * Lk; i += 64) { const int qi = i / Lk, kj = i - qi * Lk; probs[(size_t)bh * Lq * Lk + i] = Ps[qi * LDP + kj]; }
+  // ---- ctx = P V : A operand = bf16(accumulator registers 8s..8s+7), B operand = V rows in the matching permuted key order
+  f32x16 o[HD / 32];
+#pragma unroll
+  for (int c = 0; c < HD / 32; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[c][e] = 0.f;
+  const int g2 = (lane >> 4) & 1, li = lane & 15, qd = li >> 2, pp = li & 3;
+  typedef __attribute__((ext_vector_type(8))) short i16x8;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) af[jj] = (__bf16)st[t][8 * s + jj];
+#pragma unroll
+      for (int c = 0; c < HD / 32; ++c) {
+        const bf16_t* vb = Vs + (32 * t + 16 * s + 4 * hh + qd) * LDV + c * 32 + 16 * g2 + 4 * pp;
+        i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(vb));
+        i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(vb + 8 * LDV));
+        i16x8 tt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, tt), o[c], 0, 0, 0);
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < HD / 32; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int qi = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      if (qi < Lq) ctx[(size_t)(b * Lq + qi) * ldc + h * HD + c * 32 + r] = f2bf(o[c][e]);
+    }
+}
+
+extern "C" int vqa_attention_fwd_mfma(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const float* kmask, float* probs,
+                                      void* ctx, int ldc, int B, int H, int Lq, int Lk, int hd, float p, unsigned long long seed, hipStream_t st) {
+  if (!q || !k || !v || !probs || !ctx || Lq > 32 || Lk > 64 || (hd != 32 && hd != 64) || (ldq % 8) || (ldk % 8) || (ldv % 8)) return VQA_EARG;
+  const int BH = B * H;
+  const size_t shm = (size_t)4 * 64 * hd * 2 + (size_t)4 * 32 * 65 * 4;
+  dim3 grid((BH + 3) / 4);
+  if (hd == 32) hipLaunchKernelGGL(attn_fwd_mfma_kernel<32>, grid, dim3(256), shm, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, kmask, probs, (bf16_t*)ctx, ldc, BH, H, Lq, Lk, p, seed);
+  else hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, grid, dim3(256), shm, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, kmask, probs, (bf16_t*)ctx, ldc, BH, H, Lq, Lk, p, seed);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}

@@ -424,8 +424,12 @@ class HipEngine:
         probs = torch.empty((B, heads, Lq, Lk), device=Q.device, dtype=torch.float32)
         ctx = torch.empty((B * Lq, d), device=Q.device, dtype=T)
         sa = self._seed()
-        call("vqa_attention_fwd", dt(T), ptr(Q), ptr(Kt), ptr(V), ldq, ldkv, ldkv, ptr(kmask), ptr(probs), ptr(ctx), d, B, heads, Lq, Lk, hd,
-             float(p), sa)
+        if T == torch.bfloat16 and Lq <= 32 and Lk <= 64 and hd in (32, 64):
+            call("vqa_attention_fwd_mfma", ptr(Q), ptr(Kt), ptr(V), ldq, ldkv, ldkv, ptr(kmask), ptr(probs), ptr(ctx), d, B, heads, Lq, Lk, hd,
+                 float(p), sa)
+        else:
+            call("vqa_attention_fwd", dt(T), ptr(Q), ptr(Kt), ptr(V), ldq, ldkv, ldkv, ptr(kmask), ptr(probs), ptr(ctx), d, B, heads, Lq, Lk, hd,
+                 float(p), sa)
         so = self._seed()
         x1 = self._lin(ctx, attn + ".W_o.weight", p=p, seed=so, addend=q_in)
         nf, stf = self._ln(x1, norm_f)
