@@ -65,5 +65,6 @@ def test_full_size_train_step_invariants(dtype, B):
     # same state, same batch, same dropout seed -> same clip factor; weight-gradient atomics may reorder last bits only
     m2, tr2, loss2, _ = run()
     assert abs(loss - loss2) < 1e-4
-    rel = (m._flat - m2._flat).abs().max().item()
-    assert rel < 1e-5
+    # (AdamW's first step moves every weight by ~lr*sign(g): a gradient element at the noise floor may flip sign, so compare in bulk)
+    diff = (m._flat - m2._flat).abs()
+    assert diff.max().item() <= 2.5e-4 and (diff > 1e-6).float().mean().item() < 1e-3
