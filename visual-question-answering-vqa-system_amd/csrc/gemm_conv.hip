@@ -543,16 +543,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     if (st + 1 < nsteps) sstore((st + 1) & 1);
     __syncthreads();
   }
+  // flush: stage the fp32 tile through LDS (free now) so every atomic wave-instruction adds 256 CONTIGUOUS bytes of one dW row
+  // (the accumulator layout would give 4 x 64-byte segments per instruction)
+  float* Ct = reinterpret_cast<float*>(smem);                    // [BMW][BNW + 1]
+  constexpr int LDCT = BNW + 1;
+  constexpr bool STAGE = (size_t)BMW * LDCT * 4 <= (size_t)2 * BKM * (LDY + LDX) * sizeof(T);
+  if (STAGE && !p.dbg_noatomic) {
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wm * TMW + i * 16 + (lane >> 4) * 4 + r;
-        const int k2 = k20 + wn * TNW + j * 16 + (lane & 15);
-        if (n < p.N && k2 < p.Kw && !p.dbg_noatomic) atomicAdd(p.dw + (size_t)n * p.Kw + k2, acc[i][j][r]);
-      }
+        for (int r = 0; r < 4; ++r)
+          Ct[(wm * TMW + i * 16 + (lane >> 4) * 4 + r) * LDCT + wn * TNW + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+    for (int idx = tid; idx < BMW * BNW; idx += 256) {
+      const int row = idx / BNW, col = idx - row * BNW;
+      const int n = n0 + row, k2 = k20 + col;
+      if (n < p.N && k2 < p.Kw) atomicAdd(p.dw + (size_t)n * p.Kw + k2, Ct[row * LDCT + col]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wm * TMW + i * 16 + (lane >> 4) * 4 + r;
+          const int k2 = k20 + wn * TNW + j * 16 + (lane & 15);
+          if (n < p.N && k2 < p.Kw) atomicAdd(p.dw + (size_t)n * p.Kw + k2, acc[i][j][r]);
+        }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -742,7 +763,8 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
   // workgroups is the sweet spot for the 128x128 tile, ~2000 for the 64x64 tile)
   static const long target_env = getenv("VQA_WGRAD_TARGET") ? atol(getenv("VQA_WGRAD_TARGET")) : 0;
   const long target = target_env ? target_env : (big ? 1024 : 2048);
-  p.dbg_noatomic = 0;
+  static const int nostage = getenv("VQA_WGRAD_NOSTAGE") ? 1 : 0;
+  p.dbg_noatomic = nostage;      // 1: flush straight from the accumulators (A/B switch)
   long nsplit = (target + tiles - 1) / tiles;                 // aim for ~target workgroups
   long maxsplit = (M + 255) / 256;                           // at least 256 rows per split
   if (nsplit > maxsplit) nsplit = maxsplit;
