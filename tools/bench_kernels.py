@@ -65,3 +65,12 @@ if not args.only or "c64" in args.only:
     print(f"c64 patch conv fwd     {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   io {(2*x.numel())*2/t/1e12:5.2f} TB/s")
     t = timeit(lambda: K.wgrad3x3_c64(x, dy, dw, B, H, H), args.iters)
     print(f"c64 patch wgrad        {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
+
+if not args.only or "stem" in args.only:
+    H = 224
+    img = torch.randn(B, 3, H, H, device=dev)
+    dy = torch.randn(B * 112 * 112, 64, device=dev).to(T)
+    dw = torch.zeros(64, 147, device=dev)
+    fl = 2.0 * B * 112 * 112 * 64 * 147
+    t = timeit(lambda: K.stem_wgrad(img, dy, dw, B, H, H), args.iters)
+    print(f"stem wgrad (unfused)   {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   io {(img.numel()*4+dy.numel()*2)/t/1e12:5.2f} TB/s")

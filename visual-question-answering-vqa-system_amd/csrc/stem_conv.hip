@@ -7,6 +7,7 @@
 // one (channel, row): 4 aligned ds_read_b32 straight out of the patch, no im2col in memory.
 //   out  : NHWC bf16 [B][Ho][Wo][64]   (raw conv output; BN+ReLU+MaxPool is fused in vqa_stem_pool_fwd)
 //   stats: per-workgroup column sums / sums of squares [gridDim][2][64] for train-mode BatchNorm
+#include <cstdlib>
 #include "common.h"
 #include "stem_route.h"
 
@@ -148,18 +149,19 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                                                          int B, int H, int W, int Ho, int Wo, const bf16_t* __restrict__ dpool,
                                                          const uint8_t* __restrict__ idx, const float* __restrict__ coef,
-                                                         const float* __restrict__ bc, int Hp, int Wp) {
+                                                         const float* __restrict__ bc, int Hp, int Wp, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PW = 2 * Wo + 8;
-  const int MP = (Wo + 31) / 32 * 32;                                // pixels per row padded to the MFMA K step
+  const int Wh = Wo / nsplit;                                        // pixels per unit: a row is contracted in nsplit pieces so that
+  const int MP = (Wh + 31) / 32 * 32;                                // several workgroups fit one CU; padded to the MFMA K step
   bf16_t* patch = reinterpret_cast<bf16_t*>(smem);                   // [3][PRW][PW]
   bf16_t* Acol = patch + 3 * PRW * PW;                               // [MP][LDA]
   bf16_t* Dy = Acol + MP * LDA;                                      // [MP][LDD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int q = li >> 2, pp = li & 3;
   // zero the padded pixel rows once (they are never written again)
-  for (int i = tid; i < (MP - Wo) * LDA; i += 256) Acol[Wo * LDA + i] = 0;
-  for (int i = tid; i < (MP - Wo) * LDD; i += 256) Dy[Wo * LDD + i] = 0;
+  for (int i = tid; i < (MP - Wh) * LDA; i += 256) Acol[Wh * LDA + i] = 0;
+  for (int i = tid; i < (MP - Wh) * LDD; i += 256) Dy[Wh * LDD + i] = 0;
 
   // FUSED: this thread always stages channel vector cv = tid & 7 -> its BN / backward coefficients live in registers
   float f_sc[8], f_sh[8], f_a[8], f_b[8], f_c[8];
@@ -197,17 +199,18 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
       for (int row = 0; row < 3 * PRW; ++row) patch[row * PW + x] = f2bf(vals[row]);
     }
-    for (int orow = 0; orow < RBW; ++orow) {
-      __syncthreads();                                               // patch ready / previous row's MFMA reads done
-      // dy row -> LDS (16-byte vectors), im2col slice -> LDS
-      const bf16_t* dyr = dy + (((size_t)b * Ho + oh0 + orow) * Wo) * 64;
-      for (int v = tid; v < Wo * 8; v += 256) {
+    for (int unit = 0; unit < RBW * nsplit; ++unit) {
+      const int orow = unit / nsplit, px0 = (unit - orow * nsplit) * Wh;
+      __syncthreads();                                               // patch ready / previous unit's MFMA reads done
+      // dy row piece -> LDS (16-byte vectors), im2col slice -> LDS
+      const bf16_t* dyr = dy + (((size_t)b * Ho + oh0 + orow) * Wo + px0) * 64;
+      for (int v = tid; v < Wh * 8; v += 256) {
         const int px = v >> 3, cv = v & 7;
         u32x4 val = *reinterpret_cast<const u32x4*>(dyr + (size_t)px * 64 + cv * 8);      // dy row, or y row when FUSED
         if (FUSED) {
           Vec16<bf16_t> yy; yy.raw = val;
           float g8[8];
-          stem_route<bf16_t>(dpool, idx, yy, f_sc, f_sh, b, oh0 + orow, px, cv * 8, 64, Hp, Wp, g8);
+          stem_route<bf16_t>(dpool, idx, yy, f_sc, f_sh, b, oh0 + orow, px0 + px, cv * 8, 64, Hp, Wp, g8);
           Vec16<bf16_t> o;
 #pragma unroll
           for (int j = 0; j < 8; ++j) o.set(j, f_a[j] * g8[j] + f_b[j] * yy.get(j) + f_c[j]);
@@ -218,8 +221,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       }
       if (tid < 240) {                                               // 10 pixels x 24 (c,r) pairs per pass
         const int pair = tid % 24, c = pair / 7, r = pair - c * 7;
-        const bf16_t* prow = patch + (c * PRW + 2 * orow + r) * PW;
-        for (int px = tid / 24; px < Wo; px += 10) {
+        const bf16_t* prow = patch + (c * PRW + 2 * orow + r) * PW + 2 * px0;
+        for (int px = tid / 24; px < Wh; px += 10) {
           u32x4 val = {0u, 0u, 0u, 0u};
           if (pair < 21) {
             const uint32_t* ap = reinterpret_cast<const uint32_t*>(prow + 2 * px);
@@ -270,6 +273,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
+static int stem_nsplit(int Wo) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("VQA_STEM_NSPLIT"); env = e ? atoi(e) : 0; }
+  if (env > 0 && Wo % (8 * env) == 0) return env;
+  return Wo > 64 ? 2 : 1;
+}
+
 extern "C" {
 
 // number of workgroups (= rows of the statistics slab) or 0 when the shape is not supported by this kernel
@@ -299,15 +309,17 @@ int vqa_stem_conv(const float* img, const void* wstem, void* out, float* stats, 
 int vqa_stem_wgrad(const float* img, const void* dy, float* dw, int B, int H, int W, hipStream_t st) {
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   if (!img || !dy || !dw || Ho % RBW || Wo % 16 || Wo > 256) return VQA_EARG;
-  const int PW = 2 * Wo + 8, MP = (Wo + 31) / 32 * 32;
+  const int nsplit = stem_nsplit(Wo);
+  const int PW = 2 * Wo + 8, MP = (Wo / nsplit + 31) / 32 * 32;
   const size_t shm = (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
   if (shm > 160 * 1024) return VQA_EARG;
   static size_t attr = 0;
   if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
   int nblocks = B * (Ho / RBW);
-  int grid = nblocks < 512 ? nblocks : 512;
+  const int cap = 256 * (int)((160 * 1024) / shm > 4 ? 4 : (160 * 1024) / shm);
+  int grid = nblocks < cap ? nblocks : cap;
   hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)dy, dw, B, H, W, Ho, Wo,
-                     (const bf16_t*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0);
+                     (const bf16_t*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, nsplit);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // Fused stem BatchNorm/ReLU/MaxPool backward + weight gradient: dy = A*g + B*y + C is rebuilt on the fly from the raw conv
@@ -316,15 +328,17 @@ int vqa_stem_wgrad_fused(const float* img, const void* y, const void* dpool, con
                          float* dw, int B, int H, int W, hipStream_t st) {
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1, Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
   if (!img || !y || !dpool || !idx || !coef || !bcoef || !dw || Ho % RBW || Wo % 16 || Wo > 256) return VQA_EARG;
-  const int PW = 2 * Wo + 8, MP = (Wo + 31) / 32 * 32;
+  const int nsplit = stem_nsplit(Wo);
+  const int PW = 2 * Wo + 8, MP = (Wo / nsplit + 31) / 32 * 32;
   const size_t shm = (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
   if (shm > 160 * 1024) return VQA_EARG;
   static size_t attr = 0;
   if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
   int nblocks = B * (Ho / RBW);
-  int grid = nblocks < 512 ? nblocks : 512;
+  const int cap = 256 * (int)((160 * 1024) / shm > 4 ? 4 : (160 * 1024) / shm);
+  int grid = nblocks < cap ? nblocks : cap;
   hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)y, dw, B, H, W, Ho, Wo,
-                     (const bf16_t*)dpool, idx, coef, bcoef, Hp, Wp);
+                     (const bf16_t*)dpool, idx, coef, bcoef, Hp, Wp, nsplit);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 
