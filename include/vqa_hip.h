@@ -36,6 +36,7 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw, i
               int C, int Ho, int Wo, int R, int S, int stride, int pad, hipStream_t stream);
 int vqa_pack_rows(int dtype, const float* in, void* out, int N, int K, int Kp, hipStream_t stream);          /* cast + row pad   */
 int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int T, int C, int ldo, int col0, int flip, hipStream_t stream); /* out[c][col0+t*N+n] = in[n][flip?T-1-t:t][c] */
+int vqa_pack_transpose_batch(int dtype, const float* flat, void* out, const long long* desc, int nd, int total_blocks, hipStream_t stream); /* nd pieces, device table desc[nd][10] = {src_off, dst_off, N, T, C, ldo, col0, flip, blk0, 0}: every data-gradient operand of a step in one launch */
 /* stage-1 3x3/1 conv, 64->64 channels, bf16, LDS-resident input patch (models/cnn_backbone.py:182-187 at Cin=Cout=64):
  * forward (w = [Cout][R][S][Cin]) and data gradient (w = flipped+transposed pack, out += addend*(addmask>0)); weight gradient. */
 int vqa_conv3x3_c64_blocks(int B, int H, int W);

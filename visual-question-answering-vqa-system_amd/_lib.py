@@ -22,6 +22,7 @@ SIGNATURES = {
     "vqa_wgrad": [I, I, P, P, P] + [I] * 13 + [P],
     "vqa_pack_rows": [I, P, P, I, I, I, P],
     "vqa_pack_transpose": [I, P, P, I, I, I, I, I, I, P],
+    "vqa_pack_transpose_batch": [I, P, P, P, I, I, P],
     "vqa_conv3x3_c64_blocks": [I, I, I],
     "vqa_conv3x3_c64": [P, P, P, P, P, P, I, I, I, P],
     "vqa_wgrad3x3_c64": [P, P, P, I, I, I, P],

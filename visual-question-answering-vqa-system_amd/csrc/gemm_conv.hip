@@ -596,6 +596,26 @@ __global__ void pack_transpose_kernel(const float* __restrict__ in, T* __restric
   out[(size_t)c * ldo + col0 + t * N + n] = from_f<T>(in[((size_t)n * TT + ts) * C + c]);
 }
 
+// All data-gradient operands of one step in ONE launch.  desc[d] = {src_off, dst_off, N, TT, C, ldo, col0, flip, blk0, 0} (int64):
+// piece d covers workgroups blk0[d] .. blk0[d+1]-1 and is packed exactly like pack_transpose_kernel.
+template <typename T>
+__global__ void pack_transpose_batch_kernel(const float* __restrict__ flat, T* __restrict__ outbase, const long long* __restrict__ desc, int nd) {
+  int lo = 0, hi = nd - 1;                               // last piece whose blk0 <= blockIdx.x (uniform -> scalar loads)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[(size_t)mid * 10 + 8] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* d = desc + (size_t)lo * 10;
+  const float* in = flat + d[0];
+  T* out = outbase + d[1];
+  const int N = (int)d[2], TT = (int)d[3], C = (int)d[4], ldo = (int)d[5], col0 = (int)d[6], flip = (int)d[7];
+  size_t i = (size_t)(blockIdx.x - (int)d[8]) * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * TT * C) return;
+  int n = (int)(i % N); size_t r = i / N; int t = (int)(r % TT); int c = (int)(r / TT);
+  const int ts = flip ? TT - 1 - t : t;
+  out[(size_t)c * ldo + col0 + t * N + n] = from_f<T>(in[((size_t)n * TT + ts) * C + c]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -797,6 +817,17 @@ int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int TT, int
   dim3 grid((unsigned)((total + 255) / 256));
   if (dtype) hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, N, TT, C, ldo, col0, flip);
   else hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, N, TT, C, ldo, col0, flip);
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
+}
+
+// Batched form of vqa_pack_transpose: nd pieces described by a DEVICE table desc [nd][10] int64
+// {src_off (floats from flat), dst_off (elements from out), N, TT, C, ldo, col0, flip, blk0, 0}; blk0 = running sum of
+// ceil(N*TT*C / 256) and total_blocks its final value.  The caller guarantees the pieces stay inside flat / out.
+int vqa_pack_transpose_batch(int dtype, const float* flat, void* out, const long long* desc, int nd, int total_blocks, hipStream_t st) {
+  if (!flat || !out || !desc || nd <= 0 || total_blocks <= 0) return VQA_EARG;
+  if (dtype) hipLaunchKernelGGL(pack_transpose_batch_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, flat, (bf16_t*)out, desc, nd);
+  else hipLaunchKernelGGL(pack_transpose_batch_kernel<float>, dim3(total_blocks), dim3(256), 0, st, flat, (float*)out, desc, nd);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }

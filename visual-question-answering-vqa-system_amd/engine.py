@@ -33,6 +33,9 @@ class HipEngine:
         self.step_id = 0
         self.wsrc = flat
         self._wt: Dict[str, torch.Tensor] = {}
+        self._wt_plan: Dict[str, tuple] = {}      # operands packed by begin_step (filled by _packT on first use)
+        self._wt_table = None
+        self._wt_buf = None
         self.stem_w = None
         # the text encoder (many tiny, latency-bound launches) runs on its own stream beside the CNN, forward and backward
         self.side = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
@@ -48,20 +51,51 @@ class HipEngine:
     def Wm(self, name):                      # [N][K] operand in compute dtype
         return LY.mat_of(self.wsrc, self.E[name])
 
-    def Wt(self, name):                      # [C][T][N] data-gradient operand, packed once per step
-        t = self._wt.get(name)
+    def _packT(self, key, pieces, rows, ld):
+        """Data-gradient operand [rows][ld] assembled from pieces (src_offset, N, TT, C, col0, flip) of the fp32 master
+        (out[c][col0 + t*N + n] = w[n][flip ? TT-1-t : t][c]).  The first step that needs `key` packs it on demand and
+        records it in the plan; from then on begin_step() packs EVERY planned operand with one launch."""
+        t = self._wt.get(key)
         if t is None:
-            e = self.E[name]
-            n = e.shape[0]
-            c = e.shape[1]
-            tt = e.numel // (n * c)
-            t = K.pack_transpose(LY.mat_of(self.flat, e).view(n, tt, c), self.dtype)
-            self._wt[name] = t
+            t = torch.empty((rows, ld), device=self.flat.device, dtype=self.dtype)
+            for off, n, tt, c, col0, flip in pieces:
+                K.pack_transpose(self.flat[off: off + n * tt * c].view(n, tt, c), self.dtype, out=t, ldo=ld, col0=col0, flip=flip)
+            self._wt[key] = t
+            self._wt_plan[key] = (tuple(pieces), rows, ld)
+            self._wt_table = None
         return t
+
+    def Wt(self, name):                      # [C][T*N] data-gradient operand, packed once per step
+        e = self.E[name]
+        n, c = e.shape[0], e.shape[1]
+        tt = e.numel // (n * c)
+        return self._packT(name, [(e.offset, n, tt, c, 0, False)], c, tt * n)
+
+    def _pack_planned(self):
+        """One vqa_pack_transpose_batch launch for every operand recorded by _packT in earlier steps."""
+        if not self._wt_plan:
+            return
+        if self._wt_table is None or self._wt_table[0].device != self.flat.device:
+            rowsd, views, dst, blk = [], [], 0, 0
+            for key, (pieces, rows, ld) in self._wt_plan.items():
+                for off, n, tt, c, col0, flip in pieces:
+                    rowsd.append([off, dst, n, tt, c, ld, col0, int(flip), blk, 0])
+                    blk += (n * tt * c + 255) // 256
+                views.append((key, dst, rows, ld))
+                dst += (rows * ld + 7) // 8 * 8
+            self._wt_table = (torch.tensor(rowsd, dtype=torch.int64).to(self.flat.device), views, dst, blk, len(rowsd))
+            self._wt_buf = torch.empty(dst, device=self.flat.device, dtype=self.dtype)
+        table, views, total, blk, nd = self._wt_table
+        if self._wt_buf.dtype != self.dtype or self._wt_buf.device != self.flat.device:
+            self._wt_buf = torch.empty(total, device=self.flat.device, dtype=self.dtype)
+        call("vqa_pack_transpose_batch", K.dt(self.dtype), ptr(self.flat), ptr(self._wt_buf), ptr(table), nd, blk)
+        for key, dst, rows, ld in views:
+            self._wt[key] = self._wt_buf[dst: dst + rows * ld].view(rows, ld)
 
     def begin_step(self):
         """Refresh the working copies of the weights (one cast of the whole flat buffer in bf16 mode)."""
         self._wt = {}
+        self._pack_planned()
         if self.dtype == torch.bfloat16:
             if self.wsrc is self.flat or self.wsrc.numel() != self.flat.numel():
                 self.wsrc = torch.empty(self.flat.numel(), device=self.flat.device, dtype=torch.bfloat16)
@@ -96,13 +130,9 @@ class HipEngine:
         return (self.dtype == torch.bfloat16 and Cin == 64 and Cout == 64 and R == 3 and stride == 1 and K.c64_blocks(B, H, W) > 0)
 
     def _wflip(self, name):                  # [Cin][(2-r,2-s)][Cout] operand of the stride-1 data gradient as a plain 3x3 conv
-        t = self._wt.get(name + ".flip")
-        if t is None:
-            e = self.E[name]
-            n, c = e.shape[0], e.shape[1]
-            t = K.pack_transpose(LY.mat_of(self.flat, e).view(n, 9, c), self.dtype, flip=True)
-            self._wt[name + ".flip"] = t
-        return t
+        e = self.E[name]
+        n, c = e.shape[0], e.shape[1]
+        return self._packT(name + ".flip", [(e.offset, n, 9, c, 0, True)], c, 9 * n)
 
     def _conv(self, x, B, H, W, Cin, wname, Cout, R, stride, pad, stats):
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
@@ -149,11 +179,7 @@ class HipEngine:
         N = sum(self.E[w].shape[0] for w in wnames)
         M = dz.shape[0]
         K.wgrad(dz, x_in, G[e0.offset: e0.offset + N * Kin].view(N, Kin), M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype)
-        key = wnames[0] + ".multiT"
-        wt = self._wt.get(key)
-        if wt is None:
-            wt = K.pack_transpose(self.flat[e0.offset: e0.offset + N * Kin].view(N, 1, Kin), self.dtype)
-            self._wt[key] = wt
+        wt = self._packT(wnames[0] + ".multiT%d" % len(wnames), [(e0.offset, N, 1, Kin, 0, False)], Kin, N)
         dx, _, _ = K.igemm(dz, wt, M, Kin, N, K.linear_geom(M, N), dtype=self.dtype, addend=addend)
         return dx
 
@@ -659,13 +685,8 @@ class HipEngine:
             self._off_path([dyd], lambda: K.wgrad(dyd, rec["x"], LY.mat_of(G, self.E[p + ".downsample.0.weight"]), M, Cout, Cin, gd, dtype=T))
             if stride == 2 and H % 2 == 0 and W % 2 == 0:
                 # conv1 (3x3/2) and shortcut (1x1/2) data gradients in ONE launch over parity classes: no redundant taps
-                wt = self._wt.get(p + ".dgrad2")
-                if wt is None:
-                    wt = torch.empty((Cin, 10 * Cout), device=dout.device, dtype=T)
-                    K.pack_transpose(LY.mat_of(self.flat, self.E[p + ".conv1.weight"]).view(Cout, 9, Cin), T, out=wt, ldo=10 * Cout, col0=0)
-                    K.pack_transpose(LY.mat_of(self.flat, self.E[p + ".downsample.0.weight"]).view(Cout, 1, Cin), T, out=wt, ldo=10 * Cout,
-                                     col0=9 * Cout)
-                    self._wt[p + ".dgrad2"] = wt
+                wt = self._packT(p + ".dgrad2", [(self.E[p + ".conv1.weight"].offset, Cout, 9, Cin, 0, False),
+                                                 (self.E[p + ".downsample.0.weight"].offset, Cout, 1, Cin, 9 * Cout, False)], Cin, 10 * Cout)
                 dx = K.dgrad_s2(dy1, dyd, wt, B, Ho, Wo, Cout, H, W, Cin, 3, 1, dtype=T)
             else:
                 geom_dd = (B, Ho, Wo, Cout, H, W, 1, 1, stride, 0)
