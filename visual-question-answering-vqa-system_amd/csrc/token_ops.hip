@@ -114,6 +114,61 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
+// bf16, D % 8 == 0, D <= 512: lane owns channels [8*lane, 8*lane+8) -> one 16-byte load per operand per row, gamma and the
+// dgamma/dbeta partial sums stay in registers, 8 waves per workgroup are reduced in LDS before the (few) atomics.
+__global__ __launch_bounds__(512) void layernorm_bwd_bf16v_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                                  const bf16_t* __restrict__ addend, bf16_t* __restrict__ dx, float* dgamma,
+                                                                  float* dbeta, int rows, int D, float p, uint64_t seed, float* dadd, int period) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wid = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+  const int c0 = lane * 8;
+  const bool act = c0 < D;
+  float gm[8], ag[8], ab[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { gm[t] = act ? gamma[c0 + t] : 0.f; ag[t] = 0.f; ab[t] = 0.f; }
+  for (int row = wid; row < rows; row += nw) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const size_t o = (size_t)row * D + c0;
+    Vec16<bf16_t> dv = zero16<bf16_t>(), xv = zero16<bf16_t>(), av = zero16<bf16_t>();
+    if (act) {
+      dv = ldg16(dout + o); xv = ldg16(x + o);
+      if (addend) av = ldg16(addend + o);
+    }
+    float gv[8], xh[8];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float g = dv.get(t);
+      if (dadd && act) atomicAdd(dadd + (size_t)(row % period) * D + c0 + t, g);
+      if (p > 0.f) g = drop_keep(seed, o + t, p) ? g / (1.f - p) : 0.f;
+      const float h = act ? (xv.get(t) - mean) * rstd : 0.f;
+      gv[t] = g; xh[t] = h;
+      ag[t] += g * h; ab[t] += g;
+      const float gy = g * gm[t];
+      m1 += gy; m2 += gy * h;
+    }
+    m1 = wave_sum(m1) / (float)D; m2 = wave_sum(m2) / (float)D;
+    if (act) {
+      Vec16<bf16_t> ov;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) ov.set(t, rstd * (gv[t] * gm[t] - m1 - xh[t] * m2) + av.get(t));
+      stg16(dx + o, ov);
+    }
+  }
+  __shared__ float sh[2][8][512];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) { sh[0][wave][c0 + t] = ag[t]; sh[1][wave][c0 + t] = ab[t]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 512) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { a += sh[0][w][c]; b += sh[1][w][c]; }
+    atomicAdd(dgamma + c, a);
+    atomicAdd(dbeta + c, b);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Attention, one wave per (batch, head).  q/k/v/ctx are token-major with row strides ld* (elements);
 // head h occupies columns [h*hd, (h+1)*hd).  probs [B][H][Lq][Lk] fp32 holds softmax BEFORE dropout.
@@ -417,6 +472,12 @@ int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
 int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* gamma, const float* stats, const void* addend, void* dx,
                       float* dgamma, float* dbeta, int rows, int D, float p, unsigned long long seed, float* dadd, int period, hipStream_t st) {
   if (D > 512 || rows <= 0) return VQA_EARG;
+  if (dtype && D % 8 == 0) {                               // vectorised bf16 path, >= 4 rows per wave, at most one workgroup per CU
+    int gv = (rows + 31) / 32; if (gv > 256) gv = 256;
+    hipLaunchKernelGGL(layernorm_bwd_bf16v_kernel, dim3(gv), dim3(512), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, stats,
+                       (const bf16_t*)addend, (bf16_t*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period);
+    VQA_LAUNCH_CHECK(); return VQA_OK;
+  }
   const int grid = (rows + 15) / 16 > 2048 ? 2048 : (rows + 15) / 16;
   DT(hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)x, gamma, stats, (const float*)addend, (float*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period),
      hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, stats, (const bf16_t*)addend, (bf16_t*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period));
