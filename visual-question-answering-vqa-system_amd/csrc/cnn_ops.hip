@@ -17,11 +17,22 @@ __global__ void bn_reduce_partials_kernel(const float* __restrict__ part, double
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), tl = threadIdx.x >> 6;
   __shared__ double sh[2][4][64];
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int t = blockIdx.y * 4 + tl; t < tiles; t += gridDim.y * 4) {
+  if (c < C) {
+    // 8 slab rows in flight per thread: the loop is latency-bound, not bandwidth-bound
+    const int step = gridDim.y * 4;
+    int t = blockIdx.y * 4 + tl;
+    for (; t + 7 * step < tiles; t += 8 * step) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = part[((size_t)(t + u * step) * 2) * C + c]; b[u] = part[((size_t)(t + u * step) * 2 + 1) * C + c]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += (double)a[u]; q += (double)b[u]; }
+    }
+    for (; t < tiles; t += step) {
       s += (double)part[((size_t)t * 2) * C + c];
       q += (double)part[((size_t)t * 2 + 1) * C + c];
     }
+  }
   sh[0][tl][threadIdx.x & 63] = s; sh[1][tl][threadIdx.x & 63] = q;
   __syncthreads();
   if (tl == 0 && c < C) {
@@ -38,7 +49,15 @@ __global__ void bn_finalize_kernel(const double* __restrict__ acc, int G, int C,
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0, q = 0.0;
-  for (int g = 0; g < G; ++g) { s += acc[((size_t)g * 2) * C + c]; q += acc[((size_t)g * 2 + 1) * C + c]; }
+  int g = 0;
+  for (; g + 8 <= G; g += 8) {
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = acc[((size_t)(g + u) * 2) * C + c]; b[u] = acc[((size_t)(g + u) * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s += a[u]; q += b[u]; }
+  }
+  for (; g < G; ++g) { s += acc[((size_t)g * 2) * C + c]; q += acc[((size_t)g * 2 + 1) * C + c]; }
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -151,8 +170,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), tl = threadIdx.x >> 6;
   __shared__ double sh[2][16][64];
   double sg = 0.0, sx = 0.0;
-  if (c < C)
-    for (int b = tl; b < nblk; b += 16) { sg += slab[((size_t)b * 3) * C + c]; sx += slab[((size_t)b * 3 + which) * C + c]; }
+  if (c < C) {
+    int b = tl;
+    for (; b + 7 * 16 < nblk; b += 8 * 16) {               // 8 slab rows in flight per thread (latency-bound loop)
+      float a[8], x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = slab[((size_t)(b + 16 * u) * 3) * C + c]; x[u] = slab[((size_t)(b + 16 * u) * 3 + which) * C + c]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { sg += a[u]; sx += x[u]; }
+    }
+    for (; b < nblk; b += 16) { sg += slab[((size_t)b * 3) * C + c]; sx += slab[((size_t)b * 3 + which) * C + c]; }
+  }
   sh[0][tl][threadIdx.x & 63] = sg; sh[1][tl][threadIdx.x & 63] = sx;
   __syncthreads();
   if (tl != 0 || c >= C) return;

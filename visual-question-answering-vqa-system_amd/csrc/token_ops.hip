@@ -114,6 +114,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
+// out[n] += sum_b x[b][n] for x [B][N] (N % Vec16<T>::N == 0): the gradient of a row-periodic addend (position embedding),
+// one 16-byte column group per thread, grid.y slices of the batch, one atomic per column per slice.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const T* __restrict__ x, float* out, int B, size_t N) {
+  constexpr int VEC = Vec16<T>::N;
+  const size_t n0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (n0 >= N) return;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll 4
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const Vec16<T> t = ldg16(x + (size_t)b * N + n0);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] += t.get(j);
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) atomicAdd(out + n0 + j, acc[j]);
+}
+
 // bf16, D % 8 == 0, D <= 512: lane owns channels [8*lane, 8*lane+8) -> one 16-byte load per operand per row, gamma and the
 // dgamma/dbeta partial sums stay in registers, 8 waves per workgroup are reduced in LDS before the (few) atomics.
 __global__ __launch_bounds__(512) void layernorm_bwd_bf16v_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
@@ -472,6 +492,15 @@ int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
 int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* gamma, const float* stats, const void* addend, void* dx,
                       float* dgamma, float* dbeta, int rows, int D, float p, unsigned long long seed, float* dadd, int period, hipStream_t st) {
   if (D > 512 || rows <= 0) return VQA_EARG;
+  if (dadd && period > 0 && rows % period == 0 && ((size_t)period * D) % (dtype ? 8 : 4) == 0) {
+    // position-embedding gradient as its own column-sum pass (one read of dout) instead of rows*D atomics inside the LN kernel
+    const int Bb = rows / period;
+    const size_t N = (size_t)period * D, nv = N / (dtype ? 8 : 4);
+    dim3 grid((unsigned)((nv + 255) / 256), Bb < 32 ? Bb : 32);
+    DT(hipLaunchKernelGGL(colsum_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, dadd, Bb, N),
+       hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, dadd, Bb, N));
+    dadd = nullptr;
+  }
   if (dtype && D % 8 == 0) {                               // vectorised bf16 path, >= 4 rows per wave, at most one workgroup per CU
     int gv = (rows + 31) / 32; if (gv > 256) gv = 256;
     hipLaunchKernelGGL(layernorm_bwd_bf16v_kernel, dim3(gv), dim3(512), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, stats,
