@@ -121,6 +121,10 @@ int vqa_attention_fwd_mfma(const void* q, const void* k, const void* v, int ldq,
 int vqa_attention_bwd(int dtype, const void* dctx, int ldc, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
                       const float* probs, void* dq, void* dk, void* dv, int lddq, int lddk, int lddv, int B, int H, int Lq, int Lk,
                       int hd, float p, unsigned long long seed, hipStream_t stream);
+/* bf16 MFMA form of vqa_attention_bwd (Lq <= 32, Lk <= 64, hd in {32, 64}, row strides multiples of 8); same arguments minus dtype */
+int vqa_attention_bwd_mfma(const void* dctx, int ldc, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
+                           const float* probs, void* dq, void* dk, void* dv, int lddq, int lddk, int lddv, int B, int H, int Lq, int Lk,
+                           int hd, float p, unsigned long long seed, hipStream_t stream);
 /* masked mean over tokens (models/fusion.py:303-313, models/text_encoder.py:522-527) */
 int vqa_masked_pool_fwd(int dtype, const void* x, const float* mask, void* out, int ldo, int col0, int B, int L, int D, hipStream_t stream);
 int vqa_masked_pool_bwd(int dtype, const void* dpool, int ldo, int col0, const float* mask, const void* addend, void* dx,

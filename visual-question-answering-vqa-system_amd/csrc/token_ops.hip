@@ -727,3 +727,205 @@ extern "C" int vqa_attention_fwd_mfma(const void* q, const void* k, const void* 
   else hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, grid, dim3(256), shm, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, kmask, probs, (bf16_t*)ctx, ldc, BH, H, Lq, Lk, p, seed);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA attention backward: one wave per (batch, head), Lq <= 32, Lk <= 64, head dim HD in {32, 64}.
+// dP is formed TWICE from the same global 16-byte fragments (MFMAs are free at this size):
+//   orientation 1  dP^T = V . dctx^T   (lane = query, registers = keys)   -> row sums t[q], dS -> dQ = dS . K
+//   orientation 2  dP   = dctx . V^T   (lane = key,   registers = queries) -> dS, dropped P  -> dK = dS^T . Q, dV = Pd^T . dctx
+// In both, the bf16-rounded accumulator registers are the A operand of the following MFMA (as in the forward kernel) and the
+// B operand (K, Q or dctx rows) is read transposed from a wave-private LDS tile in the matching permuted order.
+// probs is the softmax BEFORE dropout saved by the forward; the dropout mask is regenerated from (seed, index).
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__device__ __forceinline__ bf16x8 attn_ldsB(const bf16_t* tile, int row0, int c, int hh, int g2, int qd, int pp) {
+  typedef __attribute__((ext_vector_type(8))) short i16x8;
+  const bf16_t* vb = tile + (row0 + 4 * hh + qd) * HD + c * 32 + 16 * g2 + 4 * pp;
+  i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(vb));
+  i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(vb + 8 * HD));
+  i16x8 tt = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, tt);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ dctx, int ldc, const bf16_t* __restrict__ q,
+                                                            const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
+                                                            const float* __restrict__ probs, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
+                                                            bf16_t* __restrict__ dv, int lddq, int lddk, int lddv, int BH, int H, int Lq, int Lk,
+                                                            float p, uint64_t seed) {
+  constexpr int LDP = 65;
+  constexpr int WAVE_BYTES = (64 + 32 + 32) * HD * 2 + 32 * LDP * 4 + 32 * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x * 4 + wave;
+  if (bh >= BH) return;                         // whole wave exits together; only wave-private LDS, no block barrier below
+  char* base = smem + (size_t)wave * WAVE_BYTES;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(base);            // [64][HD]
+  bf16_t* Qs = Ks + 64 * HD;                               // [32][HD]
+  bf16_t* Os = Qs + 32 * HD;                               // [32][HD]  (dctx)
+  float* Ps = reinterpret_cast<float*>(Os + 32 * HD);      // [32][LDP]
+  float* Ts = Ps + 32 * LDP;                               // [32]
+  const int b = bh / H, h = bh - b * H;
+  const int r = lane & 31, hh = lane >> 5;
+  const int g2 = (lane >> 4) & 1, li = lane & 15, qd = li >> 2, pp = li & 3;
+  const float inv_scale = 1.0f / sqrtf((float)HD);
+  const float keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+
+  // ---- K, Q, dctx -> LDS (16-byte vectors, padding rows zero); probabilities -> LDS
+  for (int i = lane; i < 64 * (HD / 8); i += 64) {
+    const int row = i / (HD / 8), cv = i - row * (HD / 8);
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (row < Lk) val = *reinterpret_cast<const u32x4*>(k + (size_t)(b * Lk + row) * ldk + h * HD + cv * 8);
+    *reinterpret_cast<u32x4*>(&Ks[row * HD + cv * 8]) = val;
+  }
+  for (int i = lane; i < 32 * (HD / 8); i += 64) {
+    const int row = i / (HD / 8), cv = i - row * (HD / 8);
+    u32x4 a = {0u, 0u, 0u, 0u}, o = {0u, 0u, 0u, 0u};
+    if (row < Lq) {
+      a = *reinterpret_cast<const u32x4*>(q + (size_t)(b * Lq + row) * ldq + h * HD + cv * 8);
+      o = *reinterpret_cast<const u32x4*>(dctx + (size_t)(b * Lq + row) * ldc + h * HD + cv * 8);
+    }
+    *reinterpret_cast<u32x4*>(&Qs[row * HD + cv * 8]) = a;
+    *reinterpret_cast<u32x4*>(&Os[row * HD + cv * 8]) = o;
+  }
+  for (int i = lane; i < Lq * Lk; i += 64) { const int qi = i / Lk, kj = i - qi * Lk; Ps[qi * LDP + kj] = probs[(size_t)bh * Lq * Lk + i]; }
+
+  // ---- both orientations of dP = dctx V^T from the same global fragments
+  f32x16 d1[2], d2[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { d1[t][e] = 0.f; d2[t][e] = 0.f; }
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ++ks) {
+    bf16x8 of = {};
+    if (r < Lq) of = *reinterpret_cast<const bf16x8*>(dctx + (size_t)(b * Lq + r) * ldc + h * HD + ks * 16 + 8 * hh);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 vf = {};
+      if (32 * t + r < Lk) vf = *reinterpret_cast<const bf16x8*>(v + (size_t)(b * Lk + 32 * t + r) * ldv + h * HD + ks * 16 + 8 * hh);
+      d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, of, d1[t], 0, 0, 0);      // rows = keys, cols = queries
+      d2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf, d2[t], 0, 0, 0);      // rows = queries, cols = keys
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // LDS tiles written above are visible to the whole wave
+
+  // ---- orientation 1: query = r, keys = 32t + (e&3) + 8(e>>2) + 4hh
+  const size_t prow = ((size_t)bh * Lq + r) * Lk;
+  float tq = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      const bool ok = r < Lq && key < Lk;
+      const float pr = ok ? Ps[r * LDP + key] : 0.f;
+      float ks = 1.f;
+      if (p > 0.f && ok) ks = drop_keep(seed, prow + key, p) ? keep : 0.f;
+      const float dp = ok ? d1[t][e] * ks : 0.f;
+      tq += dp * pr;
+      d1[t][e] = dp;
+    }
+  tq += __shfl_xor(tq, 32, 64);
+  if (hh == 0) Ts[r] = tq;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      const float pr = (r < Lq && key < Lk) ? Ps[r * LDP + key] : 0.f;
+      d1[t][e] = pr * (d1[t][e] - tq) * inv_scale;                     // dS[query r][key]
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // dQ = dS K
+  f32x16 oq[HD / 32];
+#pragma unroll
+  for (int c = 0; c < HD / 32; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oq[c][e] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 af;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) af[jj] = (__bf16)d1[t][8 * s2 + jj];
+#pragma unroll
+      for (int c = 0; c < HD / 32; ++c)
+        oq[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, attn_ldsB<HD>(Ks, 32 * t + 16 * s2, c, hh, g2, qd, pp), oq[c], 0, 0, 0);
+    }
+#pragma unroll
+  for (int c = 0; c < HD / 32; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int qi = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      if (qi < Lq) dq[(size_t)(b * Lq + qi) * lddq + h * HD + c * 32 + r] = f2bf(oq[c][e]);
+    }
+
+  // ---- orientation 2: key = 32t + r, queries = (e&3) + 8(e>>2) + 4hh ; dK = dS^T Q, dV = Pd^T dctx
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int key = 32 * t + r;
+    f32x16 ds2, pd2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int qi = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      const bool ok = qi < Lq && key < Lk;
+      const float pr = ok ? Ps[qi * LDP + key] : 0.f;
+      float ks = 1.f;
+      if (p > 0.f && ok) ks = drop_keep(seed, ((size_t)bh * Lq + qi) * Lk + key, p) ? keep : 0.f;
+      const float dp = ok ? d2[t][e] * ks : 0.f;
+      const float tt = ok ? Ts[qi] : 0.f;
+      ds2[e] = pr * (dp - tt) * inv_scale;
+      pd2[e] = pr * ks;
+    }
+    f32x16 okk[HD / 32], ovv[HD / 32];
+#pragma unroll
+    for (int c = 0; c < HD / 32; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { okk[c][e] = 0.f; ovv[c][e] = 0.f; }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 as, ap;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) { as[jj] = (__bf16)ds2[8 * s2 + jj]; ap[jj] = (__bf16)pd2[8 * s2 + jj]; }
+#pragma unroll
+      for (int c = 0; c < HD / 32; ++c) {
+        okk[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as, attn_ldsB<HD>(Qs, 16 * s2, c, hh, g2, qd, pp), okk[c], 0, 0, 0);
+        ovv[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, attn_ldsB<HD>(Os, 16 * s2, c, hh, g2, qd, pp), ovv[c], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < HD / 32; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int kj = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (kj < Lk) {
+          dk[(size_t)(b * Lk + kj) * lddk + h * HD + c * 32 + r] = f2bf(okk[c][e]);
+          dv[(size_t)(b * Lk + kj) * lddv + h * HD + c * 32 + r] = f2bf(ovv[c][e]);
+        }
+      }
+  }
+}
+
+extern "C" int vqa_attention_bwd_mfma(const void* dctx, int ldc, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
+                                      const float* probs, void* dq, void* dk, void* dv, int lddq, int lddk, int lddv,
+                                      int B, int H, int Lq, int Lk, int hd, float p, unsigned long long seed, hipStream_t st) {
+  if (!dctx || !q || !k || !v || !probs || !dq || !dk || !dv || Lq > 32 || Lk > 64 || (hd != 32 && hd != 64) ||
+      (ldq % 8) || (ldk % 8) || (ldv % 8) || (ldc % 8)) return VQA_EARG;
+  const int BH = B * H;
+  const size_t shm = (size_t)4 * ((64 + 32 + 32) * hd * 2 + 32 * 65 * 4 + 32 * 4);
+  dim3 grid((BH + 3) / 4);
+  if (hd == 32) {
+    static bool attr32 = false;
+    if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr32 = true; }
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel<32>, grid, dim3(256), shm, st, (const bf16_t*)dctx, ldc, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       ldq, ldk, ldv, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, BH, H, Lq, Lk, p, seed);
+  } else {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = true; }
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel<64>, grid, dim3(256), shm, st, (const bf16_t*)dctx, ldc, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       ldq, ldk, ldv, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, BH, H, Lq, Lk, p, seed);
+  }
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}

@@ -492,8 +492,12 @@ class HipEngine:
             dK, dV = dkv, dkv[:, d:]
         else:
             dQ = torch.empty((B * Lq, d), device=dev, dtype=T); dK = torch.empty((B * Lk, d), device=dev, dtype=T); dV = torch.empty((B * Lk, d), device=dev, dtype=T)
-        call("vqa_attention_bwd", dt(T), ptr(dctx), d, ptr(rec["Q"]), ptr(rec["K"]), ptr(rec["V"]), ldq, ldkv, ldkv, ptr(rec["probs"]),
-             ptr(dQ), ptr(dK), ptr(dV), ldq, ldkv, ldkv, B, heads, Lq, Lk, hd, float(p), rec["sa"])
+        if T == torch.bfloat16 and Lq <= 32 and Lk <= 64 and hd in (32, 64):
+            call("vqa_attention_bwd_mfma", ptr(dctx), d, ptr(rec["Q"]), ptr(rec["K"]), ptr(rec["V"]), ldq, ldkv, ldkv, ptr(rec["probs"]),
+                 ptr(dQ), ptr(dK), ptr(dV), ldq, ldkv, ldkv, B, heads, Lq, Lk, hd, float(p), rec["sa"])
+        else:
+            call("vqa_attention_bwd", dt(T), ptr(dctx), d, ptr(rec["Q"]), ptr(rec["K"]), ptr(rec["V"]), ldq, ldkv, ldkv, ptr(rec["probs"]),
+                 ptr(dQ), ptr(dK), ptr(dV), ldq, ldkv, ldkv, B, heads, Lq, Lk, hd, float(p), rec["sa"])
         if rec["self_attn"]:
             if fused:
                 dnq = self._lin_multi_bwd(dqkv, rec["nq"], [wq, wk, wv], G)
