@@ -27,6 +27,7 @@ struct IGemmParams {
   // LOADER_DGRAD2 (data gradient of a stride-2 conv, rows grouped by output parity class so only valid taps are issued):
   const void* a2;                               // second source (dY of the 1x1 shortcut), same geometry as a
   unsigned a_bytes, a2_bytes, w_bytes;          // buffer extents for the hardware range check
+  unsigned long long mul_howo, mul_wo;          // ceil(2^40 / d) for d = Ho*Wo, Wo (DGRAD2: (Ho/2)*(Wo/2), Wo/2): exact m / d for m*d < 2^40
   int ntaps[4]; int tap_koff[4][5]; int tap_dh[4][5]; int tap_dw[4][5]; int tap_src[4][5];
 };
 
@@ -36,11 +37,14 @@ template <> struct GT<bf16_t> { static constexpr int VEC = 8, BK = 64, MK = 32, 
 
 struct RowInfo { int pix, ih0, iw0; };
 
-__device__ __forceinline__ RowInfo decode_row(int m, int M, int HoWo, int Wo, int HW, int stride, int pad, int transposed, bool stem) {
+__device__ __forceinline__ int fast_div(int m, unsigned long long mul) { return (int)(((unsigned long long)(unsigned)m * mul) >> 40); }
+
+__device__ __forceinline__ RowInfo decode_row(int m, int M, int HoWo, int Wo, int HW, int stride, int pad, int transposed, bool stem,
+                                              unsigned long long mul_howo, unsigned long long mul_wo) {
   RowInfo ri;
   if (m >= M) { ri.pix = -1; ri.ih0 = 0; ri.iw0 = 0; return ri; }
-  int b = m / HoWo, rem = m - b * HoWo;
-  int oh = rem / Wo, ow = rem - oh * Wo;
+  int b = fast_div(m, mul_howo), rem = m - b * HoWo;
+  int oh = fast_div(rem, mul_wo), ow = rem - oh * Wo;
   ri.pix = stem ? b : b * HW;
   if (!transposed) { ri.ih0 = oh * stride - pad; ri.iw0 = ow * stride - pad; }
   else { ri.ih0 = oh + pad; ri.iw0 = ow + pad; }
@@ -93,6 +97,15 @@ template <typename T, int BM, int BN> struct IGemmCfg {
   static constexpr int SMEM = (TILES > CST + 4096 ? TILES : CST + 4096);   // BN-statistics scratch sits right after the C staging area
 };
 
+// sum over the 16 lanes of a DPP row (all 16 lanes receive it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  return v;
+}
+
 template <typename T, int BM, int BN, int LOADER>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   using G = GT<T>;
@@ -103,7 +116,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* As = reinterpret_cast<T*>(smem);
   T* Bs = As + 2 * BM * LD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA destinations and tile offsets stay in SGPRs
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
   int tile_m = blockIdx.x / tiles_n;
@@ -130,9 +144,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     if (LOADER == LOADER_DGRAD2) {
       const int r = m0 + rbase + 32 * i;
       if (r >= class_rows) { ri[i].pix = -1; ri[i].ih0 = 0; ri[i].iw0 = 0; }
-      else { const int b = r / (Hh * Wh), rem = r - b * Hh * Wh; ri[i].pix = b * p.H * p.W; ri[i].ih0 = rem / Wh; ri[i].iw0 = rem - ri[i].ih0 * Wh; }
+      else { const int b = fast_div(r, p.mul_howo), rem = r - b * Hh * Wh; ri[i].pix = b * p.H * p.W; ri[i].ih0 = fast_div(rem, p.mul_wo); ri[i].iw0 = rem - ri[i].ih0 * Wh; }
     } else {
-      ri[i] = decode_row(m0 + rbase + 32 * i, p.M, p.Ho * p.Wo, p.Wo, p.H * p.W, p.stride, p.pad, p.transposed, LOADER == LOADER_STEM);
+      ri[i] = decode_row(m0 + rbase + 32 * i, p.M, p.Ho * p.Wo, p.Wo, p.H * p.W, p.stride, p.pad, p.transposed, LOADER == LOADER_STEM,
+                         p.mul_howo, p.mul_wo);
     }
   }
 
@@ -165,22 +180,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     const int n = n0 + rbase + 32 * i;
     boff[i] = (n < p.N) ? (n * p.Kw + lvec * VEC) * (int)sizeof(T) : OOB;
   }
+  // Per-row byte offset of the lane's 16-byte chunk for filter tap (r, s): selects only, no divergent control flow.
+  // Transposed (data-gradient) gathers support stride 1 and 2 (the host entry rejects others): ih = (oh + pad - r) >> sh.
+  const int csz = p.C * (int)sizeof(T);
+  const int tsh = (p.stride == 2) ? 1 : 0, tmask = p.stride - 1;
+  const bool tr_mode = (LOADER != LOADER_DGRAD2) && p.transposed;
+  int pixoff[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) pixoff[i] = ri[i].pix * csz + lvec * VEC * (int)sizeof(T);
   auto set_tap = [&](int r, int s) {          // r,s: filter tap (NHWC) or (dh,dw) source offsets (DGRAD2)
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       bool ok = ri[i].pix >= 0;
       int ih, iw;
-      if (LOADER == LOADER_DGRAD2 || !p.transposed) { ih = ri[i].ih0 + r; iw = ri[i].iw0 + s; }
+      if (!tr_mode) { ih = ri[i].ih0 + r; iw = ri[i].iw0 + s; }
       else {
         const int th = ri[i].ih0 - r, tw = ri[i].iw0 - s;
-        ok = ok && th >= 0 && tw >= 0;
-        if (p.stride == 1) { ih = th; iw = tw; }
-        else { ih = th / p.stride; iw = tw / p.stride; ok = ok && (ih * p.stride == th) && (iw * p.stride == tw); }
+        ok = ok && (((th | tw) & tmask) == 0);
+        ih = th >> tsh; iw = tw >> tsh;            // arithmetic shift: negative stays negative and fails the range test below
       }
       ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      aoff[i] = ok ? ((ri[i].pix + ih * p.W + iw) * p.C + lvec * VEC) * (int)sizeof(T) : OOB;
+      aoff[i] = ok ? pixoff[i] + (ih * p.W + iw) * csz : OOB;
     }
   };
+  const bool a_tail = (LOADER == LOADER_NHWC) && taps == 1 && (p.C % BK) != 0;
+  const bool w_tail = (p.Kw % BK) != 0;
   int cc = 0, tap = 0, tr_ = 0, ts_ = 0;
   if (LOADER == LOADER_DGRAD2) { if (nk > 0) set_tap(p.tap_dh[cls][0], p.tap_dw[cls][0]); }
   else if (LOADER == LOADER_NHWC) set_tap(0, 0);
@@ -197,27 +221,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
       }
       return;
     }
+    // The K position inside the row goes into the instruction's SCALAR offset (not part of the hardware range check, so the
+    // out-of-range sentinel in the vector offset still yields zeros); the vector offsets are loop-invariant within a tap.
     const int kbyte = cc * BK * (int)sizeof(T);
-    const bool cok = (taps > 1 || LOADER == LOADER_DGRAD2) ? true : (cc * BK + lvec * VEC) < p.C;      // Linear K tail
     const bool second = (LOADER == LOADER_DGRAD2) && p.tap_src[cls][tap];
     const int kw = (LOADER == LOADER_DGRAD2) ? p.tap_koff[cls][tap] + cc * BK : kt * BK;
-    const bool kok = (kw + lvec * VEC) < p.Kw;
 #if defined(__HIP_DEVICE_COMPILE__)     // device pass only: the host pass cannot form LDS (address_space 3) pointers
     typedef __attribute__((address_space(3))) void* lds_ptr;
     char* abase = smem + ((size_t)((kt & 1) * BM + wave * 8) * LD) * sizeof(T);
     char* bbase = smem + ((size_t)(2 * BM + (kt & 1) * BN + wave * 8) * LD) * sizeof(T);
+    if (a_tail) {                                     // Linear whose K is not a multiple of BK: mask the chunks past the row end
+      const bool cok = (cc * BK + lvec * VEC) < p.C;
 #pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      const int vo = cok ? aoff[i] + kbyte : OOB;
-      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(abase + i * 32 * LD * (int)sizeof(T)), 16, vo, 0, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(abase + i * 32 * LD * (int)sizeof(T)), 16, vo, 0, 0, 0);
+      for (int i = 0; i < AV; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(abase + i * 32 * LD * (int)sizeof(T)), 16, cok ? aoff[i] : OOB, kbyte, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(abase + i * 32 * LD * (int)sizeof(T)), 16, aoff[i], kbyte, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(abase + i * 32 * LD * (int)sizeof(T)), 16, aoff[i], kbyte, 0, 0);
+      }
     }
+    if (w_tail) {
+      const bool kok = (kw + lvec * VEC) < p.Kw;
 #pragma unroll
-    for (int i = 0; i < BV; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(bbase + i * 32 * LD * (int)sizeof(T)), 16,
-                                               kok ? boff[i] + kw * (int)sizeof(T) : OOB, 0, 0, 0);
+      for (int i = 0; i < BV; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(bbase + i * 32 * LD * (int)sizeof(T)), 16, kok ? boff[i] : OOB,
+                                                 kw * (int)sizeof(T), 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < BV; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(bbase + i * 32 * LD * (int)sizeof(T)), 16, boff[i], kw * (int)sizeof(T), 0, 0);
+    }
 #else
-    (void)kbyte; (void)cok; (void)second; (void)kw; (void)kok;
+    (void)kbyte; (void)second; (void)kw;
 #endif
     // advance the (tap, channel-chunk) cursor for the next call
     if (++cc == cpb) {
@@ -249,7 +286,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[j], af[i], acc[i][j], 0, 0, 0);   // operands swapped: C^T
       } else {
         float af[MT], bfv[NT];
 #pragma unroll
@@ -260,7 +297,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfv[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfv[j], af[i], acc[i][j], 0, 0, 0);      // operands swapped: C^T
       }
     }
   };
@@ -274,17 +311,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: bias / relu in registers -------------------------------------------------
+  // ---- epilogue.  The MFMA operands were swapped, so a lane holds 4 CONSECUTIVE COLUMNS of one row:
+  //        acc[i][j][r] = C[m = wm*TM + i*16 + (lane & 15)][n = wn*64 + j*16 + (lane >> 4)*4 + r]
+  //      -> packed conversion and one 8-byte (bf16) / 16-byte (fp32) LDS store per (i, j) instead of four scalar ones.
+  const int lm = lane & 15, lq = lane >> 4;
   if (p.bias || p.relu) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-      const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+      const int nb = n0 + wn * 64 + j * 16 + lq * 4;
+      float bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = (p.bias && nb + r < p.N) ? p.bias[nb + r] : 0.f;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[i][j][r] + bv;
+          float v = acc[i][j][r] + bv[r];
           acc[i][j][r] = (p.relu && v < 0.f) ? 0.f : v;   // NaN-propagating ReLU like torch
         }
     }
@@ -297,8 +339,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const size_t m = (size_t)(m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r);
-          const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+          const size_t m = (size_t)(m0 + wm * TM + i * 16 + lm);
+          const int n = n0 + wn * 64 + j * 16 + lq * 4 + r;
           acc[i][j][r] = drop_keep(p.drop_seed, m * p.N + n, p.drop_p) ? acc[i][j][r] * ks : 0.f;
         }
   }
@@ -306,19 +348,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   float* red = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN>::CST);   // [WM][BN][2], after the C staging area (tiles are dead by now)
   if (p.stats) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float s = 0.f, q = 0.f;
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int r = 0; r < 4; ++r) {
+        float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { float v = acc[i][j][r]; s += v; q += v * v; }
-      s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
-      s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
-      if (lane < 16) {
-        red[(wm * BN + wn * 64 + j * 16 + lane) * 2 + 0] = s;
-        red[(wm * BN + wn * 64 + j * 16 + lane) * 2 + 1] = q;
+        for (int i = 0; i < MT; ++i) { const float v = acc[i][j][r]; s += v; q += v * v; }
+        s = row16_sum(s); q = row16_sum(q);               // the 16 rows of the MFMA tile sit on the 16 lanes of a DPP row
+        if (lm == 0) {
+          red[(wm * BN + wn * 64 + j * 16 + lq * 4 + r) * 2 + 0] = s;
+          red[(wm * BN + wn * 64 + j * 16 + lq * 4 + r) * 2 + 1] = q;
+        }
       }
-    }
   }
   // ---- stage C through LDS so global stores are full 16-byte row segments ---------------------
   constexpr int LDC = BN + VEC;
@@ -326,10 +367,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Cs[(wm * TM + i * 16 + (lane >> 4) * 4 + r) * LDC + wn * 64 + j * 16 + (lane & 15)] = from_f<T>(acc[i][j][r]);
+    for (int j = 0; j < NT; ++j) {
+      T* dst = &Cs[(wm * TM + i * 16 + lm) * LDC + wn * 64 + j * 16 + lq * 4];
+      if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+        const bf16x2_t lo = __builtin_convertvector((f32x2_t){acc[i][j][0], acc[i][j][1]}, bf16x2_t);   // v_cvt_pk_bf16_f32
+        const bf16x2_t hi = __builtin_convertvector((f32x2_t){acc[i][j][2], acc[i][j][3]}, bf16x2_t);
+        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+      } else {
+        *reinterpret_cast<f32x4*>(dst) = acc[i][j];
+      }
+    }
   __syncthreads();
   if (p.stats && tid < BN) {
     const int n = n0 + tid;
@@ -351,7 +401,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     const int n = n0 + (tid % VR) * VEC;
     if (m >= row_limit || n >= p.N) continue;
     if (LOADER == LOADER_DGRAD2) {
-      const int b = m / (Hh * Wh), rem = m - b * Hh * Wh, hh = rem / Wh, ww = rem - hh * Wh;
+      const int b = fast_div(m, p.mul_howo), rem = m - b * Hh * Wh, hh = fast_div(rem, p.mul_wo), ww = rem - hh * Wh;
       m = (b * p.Ho + 2 * hh + (cls >> 1)) * p.Wo + 2 * ww + (cls & 1);
     }
     Vec16<T> v; v.raw = *reinterpret_cast<const u32x4*>(&Cs[row * LDC + (tid % VR) * VEC]);
@@ -466,7 +516,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         rx[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsX, (c0 + c < p.C) ? base + c * (int)sizeof(T) : OOB, 0, 0);
       }
     } else {
-      RowInfo ri = decode_row(m, mend, HoWo, p.Wo, HW, p.stride, p.pad, 0, true);
+      RowInfo ri = decode_row(m, mend, HoWo, p.Wo, HW, p.stride, p.pad, 0, true, p.mul_howo, p.mul_wo);
 #pragma unroll
       for (int i = 0; i < XV; ++i) rx[i] = load_a_stem<T>(xImg, ri, k20 + (xv0 + XT * i) * VEC, p.H, p.W, p.Kw);
     }
@@ -699,6 +749,13 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
     if (loader == LOADER_NHWC && (ab >= 0x7fffffffull || wb >= 0x7fffffffull)) return VQA_EARG;
     p.a_bytes = (unsigned)(loader == LOADER_NHWC ? ab : 0); p.a2_bytes = p.a_bytes; p.w_bytes = (unsigned)wb;
   }
+  if (transposed && stride != 1 && stride != 2) return VQA_EARG;
+  {
+    const unsigned long long one = 1ull << 40;
+    if ((unsigned long long)M * (unsigned long long)(Ho * Wo) >= one) return VQA_EARG;
+    p.mul_howo = (one + (unsigned long long)(Ho * Wo) - 1) / (unsigned long long)(Ho * Wo);
+    p.mul_wo = (one + (unsigned long long)Wo - 1) / (unsigned long long)Wo;
+  }
   for (int c = 0; c < 4; ++c) p.ntaps[c] = 0;
   return dtype ? igemm_dispatch<bf16_t>(p, loader, st) : igemm_dispatch<float>(p, loader, st);
 }
@@ -737,6 +794,12 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
       for (int t = nt; t < 5; ++t) { p.tap_koff[cls][t] = 0; p.tap_dh[cls][t] = 0; p.tap_dw[cls][t] = 0; p.tap_src[cls][t] = 0; }
     }
   const int class_rows = B * (Ho / 2) * (Wo / 2);
+  {
+    const unsigned long long one = 1ull << 40, hw = (unsigned long long)(Ho / 2) * (Wo / 2);
+    if ((unsigned long long)class_rows * hw >= one) return VQA_EARG;
+    p.mul_howo = (one + hw - 1) / hw;
+    p.mul_wo = (one + (unsigned long long)(Wo / 2) - 1) / (unsigned long long)(Wo / 2);
+  }
   const int bn = N <= 64 ? 64 : 128;
   const int tiles = 4 * ((class_rows + 127) / 128) * ((N + bn - 1) / bn);
   auto go = [&](auto kern, int smem) {
