@@ -90,8 +90,11 @@ __device__ __forceinline__ Vec16<T> load_a_stem(const float* img, const RowInfo&
 // LDS tiles are unpadded 128-byte rows; the 16-byte chunk c of row r lives at chunk position c ^ (r & 7), which makes both
 // the ds_write_b128 staging stores and the ds_read_b128 / ds_read_b32 fragment reads bank-conflict free (the former
 // +16 B row padding was 2-way conflicted on every fragment read).
-template <typename T, int BM, int BN> struct IGemmCfg {
-  static constexpr int LD = GT<T>::BK;
+// Two shapes of the same kernel: 4 waves x (64 x 64) with BK = 64 (bf16) and, for 128-wide N tiles, 2 waves x (128 x 64) with
+// BK = 32: the larger wave tile reads 25% fewer LDS bytes per MFMA (the 64 x 64 shape keeps the LDS pipe as busy as the MFMA
+// pipe), its 64-byte rows use the swizzle c ^ ((r >> 2) & 3), and four 2-wave workgroups share a CU.
+template <typename T, int BM, int BN, int BK = GT<T>::BK> struct IGemmCfg {
+  static constexpr int LD = BK;
   static constexpr int TILES = 2 * (BM + BN) * LD * (int)sizeof(T);
   static constexpr int CST = BM * (BN + GT<T>::VEC) * (int)sizeof(T);
   static constexpr int SMEM = (TILES > CST + 4096 ? TILES : CST + 4096);   // BN-statistics scratch sits right after the C staging area
@@ -106,13 +109,18 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <typename T, int BM, int BN, int LOADER>
-__global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
+template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2>
+__global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   // OCC waves per SIMD (2 -> <= 256 VGPRs)
   using G = GT<T>;
-  constexpr int VEC = G::VEC, BK = G::BK, LD = BK;
-  constexpr int WN = BN / 64, WM = 4 / WN, TM = BM / WM, MT = TM / 16, NT = 4;
-  constexpr int AV = BM / 32, BV = BN / 32;
-  constexpr int SMEM = IGemmCfg<T, BM, BN>::SMEM;
+  constexpr int VEC = G::VEC, LD = BK;
+  constexpr int NTHR = NW * 64;
+  constexpr int CPR = BK / VEC;                 // 16-byte chunks per LDS row (8 or 4)
+  constexpr int RPP = NTHR / CPR;               // tile rows covered by one staging pass of the workgroup
+  constexpr int RPI = 64 / CPR;                 // tile rows written by one wave-wide LDS-DMA instruction
+  static_assert(RPP % 32 == 0 && (CPR == 8 || CPR == 4) && BN <= NTHR, "staging map");
+  constexpr int WN = BN / 64, WM = NW / WN, TM = BM / WM, MT = TM / 16, NT = 4;
+  constexpr int AV = BM / RPP, BV = BN / RPP;
+  constexpr int SMEM = IGemmCfg<T, BM, BN, BK>::SMEM;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* As = reinterpret_cast<T*>(smem);
   T* Bs = As + 2 * BM * LD;
@@ -123,7 +131,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   int tile_m = blockIdx.x / tiles_n;
   const int tile_n = blockIdx.x - tile_m * tiles_n;
   const int n0 = tile_n * BN;
-  const int vec = tid & 7, rbase = tid >> 3;
+  const int vec = tid % CPR, rbase = tid / CPR;
+  const int swz = (CPR == 8) ? (rbase & 7) : ((rbase >> 2) & 3);      // unchanged by the + 32*i of the staging passes
   const T* aT = reinterpret_cast<const T*>(p.a);
   const T* a2T = reinterpret_cast<const T*>(p.a2);
   const float* aImg = reinterpret_cast<const float*>(p.a);
@@ -142,11 +151,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 #pragma unroll
   for (int i = 0; i < AV; ++i) {
     if (LOADER == LOADER_DGRAD2) {
-      const int r = m0 + rbase + 32 * i;
+      const int r = m0 + rbase + RPP * i;
       if (r >= class_rows) { ri[i].pix = -1; ri[i].ih0 = 0; ri[i].iw0 = 0; }
       else { const int b = fast_div(r, p.mul_howo), rem = r - b * Hh * Wh; ri[i].pix = b * p.H * p.W; ri[i].ih0 = fast_div(rem, p.mul_wo); ri[i].iw0 = rem - ri[i].ih0 * Wh; }
     } else {
-      ri[i] = decode_row(m0 + rbase + 32 * i, p.M, p.Ho * p.Wo, p.Wo, p.H * p.W, p.stride, p.pad, p.transposed, LOADER == LOADER_STEM,
+      ri[i] = decode_row(m0 + rbase + RPP * i, p.M, p.Ho * p.Wo, p.Wo, p.H * p.W, p.stride, p.pad, p.transposed, LOADER == LOADER_STEM,
                          p.mul_howo, p.mul_wo);
     }
   }
@@ -173,11 +182,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   // so the XOR swizzle is applied on the SOURCE side: the lane sitting at chunk position `vec` of row r fetches chunk
   // lvec = vec ^ (r & 7).  No staging VGPRs, no ds_write; out-of-range offsets land as zeros.
   constexpr bool DMA = (LOADER != LOADER_STEM);
-  const int lvec = DMA ? (vec ^ (rbase & 7)) : vec;
+  const int lvec = DMA ? (vec ^ swz) : vec;
   int aoff[AV], boff[BV];
 #pragma unroll
   for (int i = 0; i < BV; ++i) {
-    const int n = n0 + rbase + 32 * i;
+    const int n = n0 + rbase + RPP * i;
     boff[i] = (n < p.N) ? (n * p.Kw + lvec * VEC) * (int)sizeof(T) : OOB;
   }
   // Per-row byte offset of the lane's 16-byte chunk for filter tap (r, s): selects only, no divergent control flow.
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
       for (int i = 0; i < AV; ++i) ra[i] = load_a_stem<T>(aImg, ri[i], k0 + vec * VEC, p.H, p.W, 147);
 #pragma unroll
       for (int i = 0; i < BV; ++i) {
-        const int n = n0 + rbase + 32 * i, k = k0 + vec * VEC;
+        const int n = n0 + rbase + RPP * i, k = k0 + vec * VEC;
         rb[i] = (n < p.N && k < p.Kw) ? ldg16(wT + (size_t)n * p.Kw + k) : zero16<T>();
       }
       return;
@@ -228,30 +237,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     const int kw = (LOADER == LOADER_DGRAD2) ? p.tap_koff[cls][tap] + cc * BK : kt * BK;
 #if defined(__HIP_DEVICE_COMPILE__)     // device pass only: the host pass cannot form LDS (address_space 3) pointers
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    char* abase = smem + ((size_t)((kt & 1) * BM + wave * 8) * LD) * sizeof(T);
-    char* bbase = smem + ((size_t)(2 * BM + (kt & 1) * BN + wave * 8) * LD) * sizeof(T);
+    char* abase = smem + ((size_t)((kt & 1) * BM + wave * RPI) * LD) * sizeof(T);
+    char* bbase = smem + ((size_t)(2 * BM + (kt & 1) * BN + wave * RPI) * LD) * sizeof(T);
     if (a_tail) {                                     // Linear whose K is not a multiple of BK: mask the chunks past the row end
       const bool cok = (cc * BK + lvec * VEC) < p.C;
 #pragma unroll
       for (int i = 0; i < AV; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(abase + i * 32 * LD * (int)sizeof(T)), 16, cok ? aoff[i] : OOB, kbyte, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(abase + i * RPP * LD * (int)sizeof(T)), 16, cok ? aoff[i] : OOB, kbyte, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < AV; ++i) {
-        if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(abase + i * 32 * LD * (int)sizeof(T)), 16, aoff[i], kbyte, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(abase + i * 32 * LD * (int)sizeof(T)), 16, aoff[i], kbyte, 0, 0);
+        if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(abase + i * RPP * LD * (int)sizeof(T)), 16, aoff[i], kbyte, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(abase + i * RPP * LD * (int)sizeof(T)), 16, aoff[i], kbyte, 0, 0);
       }
     }
     if (w_tail) {
       const bool kok = (kw + lvec * VEC) < p.Kw;
 #pragma unroll
       for (int i = 0; i < BV; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(bbase + i * 32 * LD * (int)sizeof(T)), 16, kok ? boff[i] : OOB,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(bbase + i * RPP * LD * (int)sizeof(T)), 16, kok ? boff[i] : OOB,
                                                  kw * (int)sizeof(T), 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < BV; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(bbase + i * 32 * LD * (int)sizeof(T)), 16, boff[i], kw * (int)sizeof(T), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(bbase + i * RPP * LD * (int)sizeof(T)), 16, boff[i], kw * (int)sizeof(T), 0, 0);
     }
 #else
     (void)kbyte; (void)second; (void)kw;
@@ -266,22 +275,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < AV; ++i)      // (rbase + 32 i) & 7 == rbase & 7
-      *reinterpret_cast<u32x4*>(&As[(buf * BM + rbase + 32 * i) * LD + ((vec ^ (rbase & 7)) * VEC)]) = ra[i].raw;
+      *reinterpret_cast<u32x4*>(&As[(buf * BM + rbase + RPP * i) * LD + ((vec ^ swz) * VEC)]) = ra[i].raw;
 #pragma unroll
     for (int i = 0; i < BV; ++i)
-      *reinterpret_cast<u32x4*>(&Bs[(buf * BN + rbase + 32 * i) * LD + ((vec ^ (rbase & 7)) * VEC)]) = rb[i].raw;
+      *reinterpret_cast<u32x4*>(&Bs[(buf * BN + rbase + RPP * i) * LD + ((vec ^ swz) * VEC)]) = rb[i].raw;
   };
   auto compute = [&](int buf) {
     const T* Ab = As + (buf * BM + wm * TM + (lane & 15)) * LD;
     const T* Bb = Bs + (buf * BN + wn * 64 + (lane & 15)) * LD;
+    const int rswz = (CPR == 8) ? (lane & 7) : ((lane >> 2) & 3);     // swizzle term of fragment row (lane & 15) + 16*i
 #pragma unroll
     for (int kk = 0; kk < BK / G::MK; ++kk) {
       if constexpr (sizeof(T) == 2) {
         bf16x8 af[MT], bfv[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 16 * LD + (((kk * 4 + (lane >> 4)) ^ (lane & 7)) * 8));
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 16 * LD + (((kk * 4 + (lane >> 4)) ^ rswz) * 8));
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bfv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 16 * LD + (((kk * 4 + (lane >> 4)) ^ (lane & 7)) * 8));
+        for (int j = 0; j < NT; ++j) bfv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 16 * LD + (((kk * 4 + (lane >> 4)) ^ rswz) * 8));
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         }
   }
   // ---- BatchNorm partial statistics (sum, sum of squares per output channel of this M tile) ----
-  float* red = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN>::CST);   // [WM][BN][2], after the C staging area (tiles are dead by now)
+  float* red = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN, BK>::CST);   // [WM][BN][2], after the C staging area (tiles are dead by now)
   if (p.stats) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
       p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = q;
     }
   }
-  constexpr int VR = BN / VEC, RP = 256 / VR;
+  constexpr int VR = BN / VEC, RP = NTHR / VR;
   T* outT = reinterpret_cast<T*>(p.out);
   const T* addT = reinterpret_cast<const T*>(p.addend);
   const T* mskT = reinterpret_cast<const T*>(p.addmask);
@@ -464,7 +474,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ys = reinterpret_cast<T*>(smem);          // [2][BKM][LDY]
   T* Xs = Ys + 2 * BKM * LDY;                  // [2][BKM][LDX]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform tile offsets stay in SGPRs
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_k = (p.Kw + BNW - 1) / BNW;
   const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
@@ -496,12 +507,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   static_assert(VRX % XT == 0 && VRX / XT == XV, "X staging map");
   const int xrow = tid / XT, xv0 = tid % XT;
   const float inv_wo = 1.0f / (float)p.Wo;
-  auto gload = [&](int ms) {
+  // dY: the lane's offsets inside a step tile never change; the step position goes into the scalar offset of the load
+  int yoff[YV];
 #pragma unroll
-    for (int i = 0; i < YV; ++i) {
-      const int idx = tid + 256 * i, row = idx / VRY, v = idx - row * VRY;
-      const int m = ms + row, n = n0 + v * VEC;
-      ry[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsY, (m < mend && n < p.N) ? (m * p.N + n) * (int)sizeof(T) : OOB, 0, 0);
+  for (int i = 0; i < YV; ++i) {
+    const int idx = tid + 256 * i, row = idx / VRY, v = idx - row * VRY, n = n0 + v * VEC;
+    yoff[i] = (n < p.N) ? (row * p.N + n) * (int)sizeof(T) : OOB;
+  }
+  auto gload = [&](int ms) {
+    const int ysoff = ms * p.N * (int)sizeof(T);
+    if (ms + BKM <= mend) {
+#pragma unroll
+      for (int i = 0; i < YV; ++i) ry[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsY, yoff[i], ysoff, 0);
+    } else {                                              // last, partial step of this chunk: rows >= mend contribute zeros
+#pragma unroll
+      for (int i = 0; i < YV; ++i) {
+        const int row = (tid + 256 * i) / VRY;
+        ry[i].raw = __builtin_amdgcn_raw_buffer_load_b128(rsY, (ms + row < mend) ? yoff[i] : OOB, ysoff, 0);
+      }
     }
     const int m = ms + xrow;
     if (LOADER == LOADER_NHWC) {
@@ -669,16 +692,16 @@ __global__ void pack_transpose_batch_kernel(const float* __restrict__ flat, T* _
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int LOADER>
+template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2>
 static int launch_igemm(const IGemmParams& p, hipStream_t st) {
-  constexpr int SMEM = IGemmCfg<T, BM, BN>::SMEM;
+  constexpr int SMEM = IGemmCfg<T, BM, BN, BK>::SMEM;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER>), dim3(tiles), dim3(256), SMEM, st, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC>), dim3(tiles), dim3(NW * 64), SMEM, st, p);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }
@@ -694,7 +717,16 @@ template <typename T>
 static int igemm_dispatch(const IGemmParams& p, int loader, hipStream_t st) {
   int bm, bn; igemm_tile(p.M, p.N, &bm, &bn);
   if (loader == LOADER_STEM) return launch_igemm<T, 128, 64, LOADER_STEM>(p, st);
-  if (bm == 128 && bn == 128) return launch_igemm<T, 128, 128, LOADER_NHWC>(p, st);
+  if (bm == 128 && bn == 128) {
+    if constexpr (sizeof(T) == 2) {
+      // 2 waves x (128 x 64), BK = 32: needs whole 64-wide K steps (the host rounds Kp to 64) -> any conv / Linear without a K tail
+      static int w2 = -1;
+      if (w2 < 0) { const char* e = getenv("VQA_IGEMM_W2"); w2 = e ? atoi(e) : 0; }
+      if (w2 == 1 && p.Kw % 64 == 0) return launch_igemm<T, 128, 128, LOADER_NHWC, 2, 32>(p, st);
+      if (w2 == 2 && p.Kw % 64 == 0) return launch_igemm<T, 128, 128, LOADER_NHWC, 4, 32, 3>(p, st);
+    }
+    return launch_igemm<T, 128, 128, LOADER_NHWC>(p, st);
+  }
   if (bm == 128 && bn == 64) return launch_igemm<T, 128, 64, LOADER_NHWC>(p, st);
   return launch_igemm<T, 64, 64, LOADER_NHWC>(p, st);
 }
