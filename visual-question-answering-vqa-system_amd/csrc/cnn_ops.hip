@@ -342,12 +342,21 @@ __global__ __launch_bounds__(256) void se_pool_fc_kernel(const T* __restrict__ x
   float s[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s[j] = 0.f;
-  if (myr < lanes_r)
-    for (int p = myr; p < HW; p += lanes_r) {
-      Vec16<T> v = ldg16(x + ((size_t)b * HW + p) * C + myv * VEC);
+  if (myr < lanes_r) {
+    const T* xb = x + (size_t)b * HW * C + myv * VEC;
+    int p = myr;
+    for (; p + 3 * lanes_r < HW; p += 4 * lanes_r) {                 // 4 independent 16-byte loads in flight per thread
+      Vec16<T> v0 = ldg16(xb + (size_t)p * C), v1 = ldg16(xb + (size_t)(p + lanes_r) * C);
+      Vec16<T> v2 = ldg16(xb + (size_t)(p + 2 * lanes_r) * C), v3 = ldg16(xb + (size_t)(p + 3 * lanes_r) * C);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += (v0.get(j) + v1.get(j)) + (v2.get(j) + v3.get(j));
+    }
+    for (; p < HW; p += lanes_r) {
+      Vec16<T> v = ldg16(xb + (size_t)p * C);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) s[j] += v.get(j);
     }
+  }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) sh[threadIdx.x * VEC + j] = s[j];
   __syncthreads();
@@ -403,13 +412,22 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
   float s[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s[j] = 0.f;
-  if (myr < lanes_r)
-    for (int p = myr; p < HW; p += lanes_r) {
-      const size_t off = ((size_t)b * HW + p) * C + myv * VEC;
+  if (myr < lanes_r) {
+    const size_t base = (size_t)b * HW * C + myv * VEC;
+    int p = myr;
+    for (; p + lanes_r < HW; p += 2 * lanes_r) {                     // 2 pixels = 4 independent 16-byte loads in flight per thread
+      const size_t o0 = base + (size_t)p * C, o1 = base + (size_t)(p + lanes_r) * C;
+      Vec16<T> d0 = ldg16(dout + o0), v0 = ldg16(x + o0), d1 = ldg16(dout + o1), v1 = ldg16(x + o1);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += d0.get(j) * v0.get(j) + d1.get(j) * v1.get(j);
+    }
+    for (; p < HW; p += lanes_r) {
+      const size_t off = base + (size_t)p * C;
       Vec16<T> d = ldg16(dout + off), v = ldg16(x + off);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) s[j] += d.get(j) * v.get(j);
     }
+  }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) sh[threadIdx.x * VEC + j] = s[j];
   __syncthreads();
@@ -454,18 +472,21 @@ __global__ void se_bwd_apply_kernel(const T* __restrict__ dout, const float* __r
 }
 
 // dw2[c][j] += sum_b dz2[b][c]*hidden[b][j] ; dw1[j][c] += sum_b dh[b][j]*pooled[b][c]
+// One thread per (j, c) pair with c fastest (coalesced dz2 / pooled rows, broadcast hidden / dh); the batch is sliced over grid.y.
 __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ dz2, const float* __restrict__ hidden, const float* __restrict__ dh,
                                 const float* __restrict__ pooled, float* dw1, float* dw2, int B, int C, int Cr) {
-  const int lane = threadIdx.x & 63;
-  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C * Cr) return;
+  const int j = i / C, c = i - j * C;
+  const int per = (B + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(B, b0 + per);
   float t2 = 0.f, t1 = 0.f;
-  { const int c = i / Cr, j = i - c * Cr;
-    for (int b = lane; b < B; b += 64) t2 += dz2[(size_t)b * C + c] * hidden[(size_t)b * Cr + j]; }
-  { const int j = i / C, c = i - j * C;
-    for (int b = lane; b < B; b += 64) t1 += dh[(size_t)b * Cr + j] * pooled[(size_t)b * C + c]; }
-  t2 = wave_sum(t2); t1 = wave_sum(t1);
-  if (lane == 0) { dw2[i] += t2; dw1[i] += t1; }
+#pragma unroll 4
+  for (int b = b0; b < b1; ++b) {
+    t2 += dz2[(size_t)b * C + c] * hidden[(size_t)b * Cr + j];
+    t1 += dh[(size_t)b * Cr + j] * pooled[(size_t)b * C + c];
+  }
+  atomicAdd(dw2 + (size_t)c * Cr + j, t2);
+  atomicAdd(dw1 + (size_t)j * C + c, t1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -717,7 +738,7 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   const size_t nvec = (size_t)B * HW * C / VEC;
   DT(hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)dout, scale, dpool, (float*)dx, nvec, HW, C),
      hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)dout, scale, dpool, (bf16_t*)dx, nvec, HW, C));
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 3) / 4), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 255) / 256, B >= 64 ? 8 : 1), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 
