@@ -148,7 +148,7 @@ def main():
         tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(tpath) and args.batch == 512 and args.dtype == "bf16":
             for kname, v in json.load(open(tpath))["kernels"].items():
-                if name in kname:
+                if name.rstrip('>') in kname:      # the PROFILE name is a prefix of the full template instantiation
                     traffic = round(v["hbm_bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                 "frac": round(ach / PEAK[args.dtype], 4), "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE)",
