@@ -125,6 +125,9 @@ int vqa_attention_bwd(int dtype, const void* dctx, int ldc, const void* q, const
 int vqa_attention_bwd_mfma(const void* dctx, int ldc, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
                            const float* probs, void* dq, void* dk, void* dv, int lddq, int lddk, int lddv, int B, int H, int Lq, int Lk,
                            int hd, float p, unsigned long long seed, hipStream_t stream);
+/* Device-side accuracy counters: counters[3] (u64) += {top-1 correct, top-5 correct, samples} for fp32 logits [B][N] and i64 targets.
+ * Replaces the argmax/topk + .cpu() + .item() of VQAAccuracy.update (utils/metrics.py:55-94); ties resolve to the lowest index. */
+int vqa_accuracy_update(const float* logits, const long long* targets, unsigned long long* counters, int B, int N, hipStream_t stream);
 /* masked mean over tokens (models/fusion.py:303-313, models/text_encoder.py:522-527) */
 int vqa_masked_pool_fwd(int dtype, const void* x, const float* mask, void* out, int ldo, int col0, int B, int L, int D, hipStream_t stream);
 int vqa_masked_pool_bwd(int dtype, const void* dpool, int ldo, int col0, const float* mask, const void* addend, void* dx,

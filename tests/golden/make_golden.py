@@ -130,9 +130,42 @@ def gen_overfit():
     print("overfit acc", acc, "final loss", losses[-1])
 
 
+def gen_metrics():
+    """utils/metrics.py VQAAccuracy on seeded logits: several batches, well-separated values (no ties) plus one batch of
+    duplicated maxima away from the target (so tie ORDER, which torch.topk leaves unspecified, cannot matter)."""
+    from utils.metrics import VQAAccuracy  # the reference
+    g = torch.Generator().manual_seed(11)
+    acc = VQAAccuracy()
+    per_batch = []
+    batches = []
+    for B, C in ((64, 1000), (7, 10), (33, 1000), (5, 6)):
+        logits = torch.randn(B, C, generator=g)
+        targets = torch.randint(0, C, (B,), generator=g)
+        # make ~1/3 of the rows top-1 hits and ~1/3 rank 1..4
+        for b in range(B):
+            if b % 3 == 0:
+                logits[b, targets[b]] = logits[b].max() + 1.0
+            elif b % 3 == 1:
+                v, _ = logits[b].sort(descending=True)
+                logits[b, targets[b]] = (v[2] + v[3]) / 2 if C > 4 else v[1] - 1e-3
+        acc.update(logits, targets)
+        per_batch.append([acc.correct, acc.correct_top5, acc.total])
+        batches.append((logits.numpy(), targets.numpy()))
+    out = {"running": np.array(per_batch, dtype=np.int64)}
+    for i, (l, t) in enumerate(batches):
+        out[f"logits{i}"] = l; out[f"targets{i}"] = t
+    m = acc.compute()
+    out["accuracy"] = np.array([m["accuracy"], m["accuracy_top5"]])
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+    print("metrics", per_batch, m["accuracy"], m["accuracy_top5"])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        gen_metrics(); sys.exit(0)
     gen_full_eval()
     gen_full_train("full_train", O.full_config(dropout=0.0, answer_dropout=0.0), seed=2, B=4)
     gen_full_train("small_train", O.full_config(dropout=0.0, answer_dropout=0.0, vocab_size=100, num_answers=10,
                                                 embed_dim=32), seed=3, B=2, image_size=64, seq_len=10, vocab=100)
     gen_overfit()
+    gen_metrics()

@@ -27,3 +27,19 @@ def load_dropin():
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_dropin_metrics():
+    """Import the drop-in `utils.metrics` (device-side VQAAccuracy) without disturbing an already imported `utils` package."""
+    import importlib.util
+    import os
+    import sys
+    name = "vqa_hip_dropin_utils_metrics"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(dropin_path(), "utils", "metrics.py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod

@@ -55,6 +55,7 @@ SIGNATURES = {
     "vqa_attention_fwd": [I, P, P, P, I, I, I, P, P, P, I, I, I, I, I, I, F, ULL, P],
     "vqa_attention_fwd_mfma": [P, P, P, I, I, I, P, P, P, I, I, I, I, I, I, F, ULL, P],
     "vqa_attention_bwd": [I, P, I, P, P, P, I, I, I, P, P, P, P, I, I, I, I, I, I, I, I, F, ULL, P],
+    "vqa_accuracy_update": [P, P, P, I, I, P],
     "vqa_attention_bwd_mfma": [P, I, P, P, P, I, I, I, P, P, P, P, I, I, I, I, I, I, I, I, F, ULL, P],
     "vqa_masked_pool_fwd": [I, P, P, P, I, I, I, I, I, P],
     "vqa_masked_pool_bwd": [I, P, I, I, P, P, P, I, I, I, P],

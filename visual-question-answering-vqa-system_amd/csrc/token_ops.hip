@@ -929,3 +929,39 @@ extern "C" int vqa_attention_bwd_mfma(const void* dctx, int ldc, const void* q, 
   }
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Device-side accuracy counters (utils/metrics.py:55-94 VQAAccuracy.update without its .cpu()/.item() syncs).
+// One wave per sample: rank of the target = #{j : x[j] > x[t]} + #{j < t : x[j] == x[t]} (ties resolve to the lowest index,
+// like argmax); top-1 correct <=> rank == 0, top-5 correct <=> rank < 5.  counters = {correct, correct_top5, total} (u64, +=).
+// A target outside [0, N) counts as wrong (the reference's comparison can never match it either).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void accuracy_kernel(const float* __restrict__ logits, const long long* __restrict__ targets,
+                                                       unsigned long long* counters, int B, int N) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= B) return;
+  const long long t = targets[row];
+  const float* x = logits + (size_t)row * N;
+  float cnt = 0.f;
+  const bool valid = t >= 0 && t < N;
+  if (valid) {
+    const float xt = x[t];
+    for (int j = lane; j < N; j += 64) {
+      const float v = x[j];
+      cnt += (v > xt || (v == xt && j < (int)t)) ? 1.f : 0.f;
+    }
+  }
+  cnt = wave_sum(cnt);
+  if (lane == 0) {
+    if (valid && cnt < 0.5f) atomicAdd(counters + 0, 1ull);
+    if (valid && cnt < 4.5f) atomicAdd(counters + 1, 1ull);
+    atomicAdd(counters + 2, 1ull);
+  }
+}
+
+extern "C" int vqa_accuracy_update(const float* logits, const long long* targets, unsigned long long* counters, int B, int N, hipStream_t st) {
+  if (!logits || !targets || !counters || B <= 0 || N <= 0) return VQA_EARG;
+  hipLaunchKernelGGL(accuracy_kernel, dim3((B + 3) / 4), dim3(256), 0, st, logits, targets, counters, B, N);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}

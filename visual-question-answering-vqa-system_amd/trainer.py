@@ -74,8 +74,9 @@ class HipTrainer:
         self.reducer = GradBucketReducer(self.G, self.buckets, process_group, overlap)
         self.world = self.reducer.world
 
-    def step(self, images, token_ids, attention_mask, targets):
-        """One full train step; returns (loss device scalar, logits fp32)."""
+    def step(self, images, token_ids, attention_mask, targets, metrics=None):
+        """One full train step; returns (loss device scalar, logits fp32).  `metrics`: optional device-side accuracy tracker
+        (dropin/utils/metrics.py VQAAccuracy) updated from the logits without a host sync (train.py:211-212 does two)."""
         eng, T = self.engine, self.engine.dtype
         self.G.zero_()
         self.loss.zero_()
@@ -84,6 +85,8 @@ class HipTrainer:
         B, N = logits_f.shape
         dlogits = torch.empty((B, N), device=images.device, dtype=torch.float32)
         call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0)
+        if metrics is not None:
+            metrics.update(logits_f, targets)
         eng.backward(tape, dlogits, self.G, on_segment=self.reducer.on_segment if self.world > 1 else None)
         gscale = self.reducer.finish()
         call("vqa_sumsq", ptr(self.G), self.G.numel(), ptr(self.sumsq))
