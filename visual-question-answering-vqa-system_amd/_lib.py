@@ -23,6 +23,7 @@ SIGNATURES = {
     "vqa_pack_rows": [I, P, P, I, I, I, P],
     "vqa_pack_transpose": [I, P, P, I, I, I, I, I, I, P],
     "vqa_pack_transpose_batch": [I, P, P, P, I, I, P],
+    "vqa_fold_bn_batch": [I, P, P, P, P, I, I, F, P],
     "vqa_conv3x3_c64_blocks": [I, I, I],
     "vqa_conv3x3_c64": [P, P, P, P, P, P, I, I, I, P],
     "vqa_wgrad3x3_c64": [P, P, P, I, I, I, P],

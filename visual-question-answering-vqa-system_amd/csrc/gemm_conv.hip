@@ -337,7 +337,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[i][j][r] + bv[r];
-          acc[i][j][r] = (p.relu && v < 0.f) ? 0.f : v;   // NaN-propagating ReLU like torch
+          acc[i][j][r] = (p.relu == 1 && v < 0.f) ? 0.f : v;   // NaN-propagating ReLU like torch
         }
     }
   }
@@ -428,11 +428,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
           for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + av.get(j));
         }
       }
+      if (p.relu == 2) {                               // ReLU AFTER the addend: relu(conv + bias + residual), the folded eval block
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { const float x = v.get(j); v.set(j, x < 0.f ? 0.f : x); }
+      }
       stg16(outT + off, v);
     } else {
       for (int j = 0; j < VEC && n + j < p.N; ++j) {
         float x = v.get(j);
         if (addT) { float a = to_f<T>(addT[off + j]); x += (!mskT || to_f<T>(mskT[off + j]) > 0.f) ? a : 0.f; }
+        if (p.relu == 2 && x < 0.f) x = 0.f;
         outT[off + j] = from_f<T>(x);
       }
     }
@@ -689,6 +694,36 @@ __global__ void pack_transpose_batch_kernel(const float* __restrict__ flat, T* _
   out[(size_t)c * ldo + col0 + t * N + n] = from_f<T>(in[((size_t)n * TT + ts) * C + c]);
 }
 
+// Eval-mode Conv+BatchNorm folding for every conv of the network in ONE launch:
+//   w'[n][k] = w[n][k] * gamma[n] / sqrt(running_var[n] + eps)   (cast to T),   b'[n] = beta[n] - running_mean[n] * (same scale)
+// desc[d] = {w_off, gamma_off, beta_off (floats from flat), running_mean ptr, running_var ptr, N, K, dst_off (elements of wout),
+//            bias_off (floats of bout), blk0}; piece d covers workgroups blk0[d] .. blk0[d+1]-1.
+template <typename T>
+__global__ void fold_bn_batch_kernel(const float* __restrict__ flat, T* __restrict__ wout, float* __restrict__ bout,
+                                     const long long* __restrict__ desc, int nd, float eps) {
+  int lo = 0, hi = nd - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[(size_t)mid * 10 + 9] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* d = desc + (size_t)lo * 10;
+  const float* w = flat + d[0];
+  const float* gamma = flat + d[1];
+  const float* beta = flat + d[2];
+  const float* rm = reinterpret_cast<const float*>(d[3]);
+  const float* rv = reinterpret_cast<const float*>(d[4]);
+  const int N = (int)d[5], K = (int)d[6];
+  const size_t i = (size_t)(blockIdx.x - (int)d[9]) * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * K) return;
+  const int n = (int)(i / K);
+  const float sc = gamma[n] / sqrtf(rv[n] + eps);
+  wout[d[7] + i] = from_f<T>(w[i] * sc);
+  if (i < (size_t)N) {
+    const float s2 = gamma[i] / sqrtf(rv[i] + eps);
+    bout[d[8] + i] = beta[i] - rm[i] * s2;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -912,6 +947,17 @@ int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int TT, int
   dim3 grid((unsigned)((total + 255) / 256));
   if (dtype) hipLaunchKernelGGL(pack_transpose_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)out, N, TT, C, ldo, col0, flip);
   else hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, N, TT, C, ldo, col0, flip);
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
+}
+
+// Fold eval-mode BatchNorm into the preceding conv's weights for nd convs at once; desc is a DEVICE table [nd][10] int64
+// {w_off, gamma_off, beta_off, running_mean pointer, running_var pointer, N, K, dst_off, bias_off, blk0} (see the kernel).
+int vqa_fold_bn_batch(int dtype, const float* flat, void* wout, float* bout, const long long* desc, int nd, int total_blocks, float eps,
+                      hipStream_t st) {
+  if (!flat || !wout || !bout || !desc || nd <= 0 || total_blocks <= 0) return VQA_EARG;
+  if (dtype) hipLaunchKernelGGL(fold_bn_batch_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, flat, (bf16_t*)wout, bout, desc, nd, eps);
+  else hipLaunchKernelGGL(fold_bn_batch_kernel<float>, dim3(total_blocks), dim3(256), 0, st, flat, (float*)wout, bout, desc, nd, eps);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }

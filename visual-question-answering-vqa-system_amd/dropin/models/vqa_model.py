@@ -134,6 +134,7 @@ class VQAModel(nn.Module):
         self._on_segment = None
         self._last_aux = None
         self._tapes: Dict[int, Any] = {}
+        self._graphs: Dict[Any, Any] = {}           # captured inference graphs, one per input shape (forward_graphed)
         self._tape_seq = 0
         self._handle = _NEXT_HANDLE[0]
         _NEXT_HANDLE[0] += 1
@@ -191,6 +192,39 @@ class VQAModel(nn.Module):
         else:
             logits, aux, _ = eng.forward(images, token_ids, maskf, self.training, return_aux, need_tape=False)
         return (logits, aux) if return_aux else (logits, None)
+
+    def forward_graphed(self, images: torch.Tensor, token_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Latency mode for serving (api/inference.py:196-323 calls predict at B = 1 ... 64, where ~190 launches of a few
+        microseconds each are host-bound): the eval forward (Conv+BN folded) is captured once per input shape into a HIP graph
+        and replayed; inputs are copied into the graph's static buffers.  Inference only: eval mode, no autograd, logits only."""
+        if self.training:
+            raise RuntimeError("forward_graphed is the inference path: call model.eval() first")
+        if not images.is_cuda:
+            raise RuntimeError("VQAModel (HIP) got CPU inputs; this implementation only runs on an MI355X (no CPU fallback)")
+        key = (tuple(images.shape), tuple(token_ids.shape), attention_mask is not None, self._flat.data_ptr())
+        g = self._graphs.get(key)
+        if g is None:
+            st_img = images.detach().clone().contiguous().float()
+            st_ids = token_ids.detach().clone().contiguous().long()
+            st_msk = None if attention_mask is None else attention_mask.detach().clone().contiguous().float()
+            with torch.no_grad():
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                       # warm-up off the default stream, as graph capture requires
+                    for _ in range(2):
+                        self.forward(st_img, st_ids, st_msk)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out, _ = self.forward(st_img, st_ids, st_msk)
+            g = (graph, st_img, st_ids, st_msk, out)
+            self._graphs[key] = g
+        graph, st_img, st_ids, st_msk, out = g
+        st_img.copy_(images); st_ids.copy_(token_ids)
+        if st_msk is not None:
+            st_msk.copy_(attention_mask)
+        graph.replay()
+        return out
 
     def predict(self, images, token_ids, attention_mask=None, top_k: int = 5):
         self.eval()

@@ -36,6 +36,8 @@ class HipEngine:
         self._wt_plan: Dict[str, tuple] = {}      # operands packed by begin_step (filled by _packT on first use)
         self._wt_table = None
         self._wt_buf = None
+        self.fold_eval = True                     # inference (eval, no tape): Conv+BN folded, BN never runs as its own pass
+        self._fold = None                         # (key, table, nd, blocks, wbuf, bbuf, views)
         self.stem_w = None
         # the text encoder (many tiny, latency-bound launches) runs on its own stream beside the CNN, forward and backward
         self.side = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
@@ -91,6 +93,36 @@ class HipEngine:
         call("vqa_pack_transpose_batch", K.dt(self.dtype), ptr(self.flat), ptr(self._wt_buf), ptr(table), nd, blk)
         for key, dst, rows, ld in views:
             self._wt[key] = self._wt_buf[dst: dst + rows * ld].view(rows, ld)
+
+    def _fold_bn(self):
+        """Eval-mode Conv+BN folding of every residual-block conv in one launch (BN eval semantics of
+        models/cnn_backbone.py:164-197 with running statistics).  Returns {conv weight name: (folded [N][K] operand, bias [N])}."""
+        pairs = []
+        for s_ in range(1, 5):
+            for b in range(2):
+                p = f"image_encoder.stage{s_}.blocks.{b}"
+                pairs += [(p + ".conv1.weight", p + ".bn1"), (p + ".conv2.weight", p + ".bn2")]
+                if (p + ".downsample.0.weight") in self.E:
+                    pairs.append((p + ".downsample.0.weight", p + ".downsample.1"))
+        key = (self.flat.data_ptr(), str(self.dtype)) + tuple(self.buf[bn + ".running_mean"].data_ptr() for _, bn in pairs)
+        if self._fold is None or self._fold[0] != key:
+            rows, views, woff, boff, blk = [], {}, 0, 0, 0
+            for wname, bn in pairs:
+                e = self.E[wname]
+                n = e.shape[0]
+                k = e.numel // n
+                rows.append([e.offset, self.E[bn + ".weight"].offset, self.E[bn + ".bias"].offset,
+                             self.buf[bn + ".running_mean"].data_ptr(), self.buf[bn + ".running_var"].data_ptr(), n, k, woff, boff, blk])
+                views[wname] = (woff, boff, n, k)
+                woff += (n * k + 7) // 8 * 8
+                boff += (n + 7) // 8 * 8
+                blk += (n * k + 255) // 256
+            dev = self.flat.device
+            self._fold = (key, torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), blk,
+                          torch.empty(woff, device=dev, dtype=self.dtype), torch.empty(boff, device=dev, dtype=torch.float32), views)
+        _, table, nd, blk, wbuf, bbuf, views = self._fold
+        call("vqa_fold_bn_batch", K.dt(self.dtype), ptr(self.flat), ptr(wbuf), ptr(bbuf), ptr(table), nd, blk, 1e-5)
+        return {w: (wbuf[wo: wo + n * k].view(n, k), bbuf[bo: bo + n]) for w, (wo, bo, n, k) in views.items()}
 
     def begin_step(self):
         """Refresh the working copies of the weights (one cast of the whole flat buffer in bf16 mode)."""
@@ -317,6 +349,7 @@ class HipEngine:
         H, W, C = Hp, Wp, 64
 
         # ---- residual stages, A2-A5
+        folded = self._fold_bn() if (self.fold_eval and not training and not need_tape) else None
         tape["stages"] = []
         for s, Cout in enumerate(LY.STAGE_CHANNELS, start=1):
             srec = {"blocks": []}
@@ -324,6 +357,20 @@ class HipEngine:
                 p = f"image_encoder.stage{s}.blocks.{b}"
                 stride = 2 if (b == 0 and s > 1) else 1
                 Cin = C
+                if folded is not None:
+                    # inference: a1 = relu(conv1'(x) + b1); out = relu(conv2'(a1) + b2 + shortcut) -- two or three launches, no BN pass
+                    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+                    M = B * Ho * Wo
+                    w1, b1 = folded[p + ".conv1.weight"]
+                    w2, b2 = folded[p + ".conv2.weight"]
+                    a1, _, _ = K.igemm(x, w1, M, Cout, 9 * Cin, (B, H, W, Cin, Ho, Wo, 3, 3, stride, 1), dtype=T, bias=b1, relu=1)
+                    res = x
+                    if (p + ".downsample.0.weight") in self.E:
+                        wd, bd = folded[p + ".downsample.0.weight"]
+                        res, _, _ = K.igemm(x, wd, M, Cout, Cin, (B, H, W, Cin, Ho, Wo, 1, 1, stride, 0), dtype=T, bias=bd)
+                    out, _, _ = K.igemm(a1, w2, M, Cout, 9 * Cout, (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1), dtype=T, bias=b2, addend=res, relu=2)
+                    x, H, W, C = out, Ho, Wo, Cout
+                    continue
                 y1, st1, mt1, g1, Ho, Wo = self._conv(x, B, H, W, Cin, p + ".conv1.weight", Cout, 3, stride, 1, training)
                 M = B * Ho * Wo
                 c1 = self._bn_coef(p + ".bn1", st1, mt1, Cout, M, training)
