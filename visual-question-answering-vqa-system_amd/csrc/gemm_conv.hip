@@ -511,7 +511,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int XT = 256 / BKM;                       // threads per X row
   static_assert(VRX % XT == 0 && VRX / XT == XV, "X staging map");
   const int xrow = tid / XT, xv0 = tid % XT;
-  const float inv_wo = 1.0f / (float)p.Wo;
+  const float inv_wo = 1.0f / (float)p.Wo, inv_ho = 1.0f / (float)p.Ho;
+  int xb, xoh, xow;                                     // pixel of row xrow at the first step of this chunk (exact magic division, once)
+  {
+    const int m = mbeg + xrow;
+    xb = fast_div(m, p.mul_howo);
+    const int rem = m - xb * HoWo;
+    xoh = fast_div(rem, p.mul_wo); xow = rem - xoh * p.Wo;
+  }
   // dY: the lane's offsets inside a step tile never change; the step position goes into the scalar offset of the load
   int yoff[YV];
 #pragma unroll
@@ -533,11 +540,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
     const int m = ms + xrow;
     if (LOADER == LOADER_NHWC) {
-      const int b = (int)(((unsigned long long)m * p.mul_howo) >> 40), rem = m - b * HoWo;
-      const int oh = (int)(((float)rem + 0.5f) * inv_wo), ow = rem - oh * p.Wo;      // exact: rem < 2^16
-      const int ih = oh * p.stride - p.pad + tr, iw = ow * p.stride - p.pad + ts;
+      // (xb, xoh, xow) is this thread's pixel for the current step; 24-bit multiplies (all factors < 2^24) instead of the
+      // quarter-rate 32-bit ones, and the step-to-step update below needs no wide division
+      const int ih = __mul24(xoh, p.stride) - p.pad + tr, iw = __mul24(xow, p.stride) - p.pad + ts;
       const bool ok = m < mend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const int base = ok ? ((b * HW + ih * p.W + iw) * p.C + c0) * (int)sizeof(T) : OOB;
+      const int pixel = __mul24(xb, HW) + __mul24(ih, p.W) + iw;
+      const int base = ok ? (__mul24(pixel, p.C) + c0) * (int)sizeof(T) : OOB;
+      {                                                   // advance to the next step's pixel: m += BKM
+        xow += BKM;
+        const int q = (int)(((float)xow + 0.5f) * inv_wo);  // exact for these magnitudes: (x + 0.5) / d is never an integer
+        xow -= __mul24(q, p.Wo); xoh += q;
+        const int q2 = (int)(((float)xoh + 0.5f) * inv_ho);
+        xoh -= __mul24(q2, p.Ho); xb += q2;
+      }
 #pragma unroll
       for (int i = 0; i < XV; ++i) {
         const int c = (xv0 + XT * i) * VEC;
@@ -899,6 +914,7 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
     const size_t yb = (size_t)M * N * es, xb = (size_t)B * H * W * C * es;
     if (yb >= 0x7fffffffull || (loader == LOADER_NHWC && xb >= 0x7fffffffull)) return VQA_EARG;
     if ((double)M * ((double)Ho * Wo) >= 1099511627776.0) return VQA_EARG;
+    if (loader == LOADER_NHWC && (long)B * H * W >= (1l << 23)) return VQA_EARG;   // pixel indices go through 24-bit multiplies
     p.dy_bytes = (unsigned)yb; p.x_bytes = (unsigned)(loader == LOADER_NHWC ? xb : 0);
     const unsigned long long one = 1ull << 40;
     p.mul_howo = (one + (unsigned long long)(Ho * Wo) - 1) / (unsigned long long)(Ho * Wo);
