@@ -922,13 +922,15 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
   }
   // tile: 128x128 when both dims allow it and (for multi-tap convs) a tile stays inside one tap
   const bool big = (N >= 128) && (R * S > 1 ? (C % 128 == 0) : (Kw >= 128));
-  const int bmw = big ? 128 : 64, bnw = big ? 128 : 64;
+  // 128 x 64 when only the dY side is wide (64-channel inputs: stage-2 entry conv and its 1x1 shortcut)
+  const bool mid = !big && loader == LOADER_NHWC && (N >= 128) && (R * S > 1 ? (C % 64 == 0) : (Kw >= 64));
+  const int bmw = (big || mid) ? 128 : 64, bnw = big ? 128 : 64;
   if (loader == LOADER_NHWC && R * S > 1 && (C % bnw)) return VQA_EARG;
   const long tiles = (long)((N + bmw - 1) / bmw) * ((Kw + bnw - 1) / bnw);
   // split-K factor: more workgroups hide latency, but every split adds a tile's worth of fp32 atomics (measured: ~1000
   // workgroups is the sweet spot for the 128x128 tile, ~2000 for the 64x64 tile)
   static const long target_env = getenv("VQA_WGRAD_TARGET") ? atol(getenv("VQA_WGRAD_TARGET")) : 0;
-  const long target = target_env ? target_env : (big ? 1024 : 2048);
+  const long target = target_env ? target_env : (big ? 1024 : (mid ? 1536 : 2048));
   static const int nostage = getenv("VQA_WGRAD_NOSTAGE") ? 1 : 0;
   p.dbg_noatomic = nostage;      // 1: flush straight from the accumulators (A/B switch)
   long nsplit = (target + tiles - 1) / tiles;                 // aim for ~target workgroups
@@ -943,6 +945,8 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
     return dtype ? launch_wgrad<bf16_t, 64, 64, LOADER_STEM>(p, (int)nsplit, st) : launch_wgrad<float, 64, 64, LOADER_STEM>(p, (int)nsplit, st);
   if (big)
     return dtype ? launch_wgrad<bf16_t, 128, 128, LOADER_NHWC>(p, (int)nsplit, st) : launch_wgrad<float, 128, 128, LOADER_NHWC>(p, (int)nsplit, st);
+  if (mid)
+    return dtype ? launch_wgrad<bf16_t, 128, 64, LOADER_NHWC>(p, (int)nsplit, st) : launch_wgrad<float, 128, 64, LOADER_NHWC>(p, (int)nsplit, st);
   return dtype ? launch_wgrad<bf16_t, 64, 64, LOADER_NHWC>(p, (int)nsplit, st) : launch_wgrad<float, 64, 64, LOADER_NHWC>(p, (int)nsplit, st);
 }
 

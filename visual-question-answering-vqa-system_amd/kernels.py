@@ -170,9 +170,10 @@ def wgrad(dy, x, dw, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC):
     if PROFILE is not None:
         e1.record()
         big = N >= 128 and ((C % 128 == 0) if R * S > 1 else (Kw >= 128)) and loader == LOADER_NHWC
-        t = 128 if big else 64
+        mid = (not big) and loader == LOADER_NHWC and N >= 128 and ((C % 64 == 0) if R * S > 1 else (Kw >= 64))
+        t, t2 = (128 if (big or mid) else 64), (128 if big else 64)
         es = 2 if dtype == torch.bfloat16 else 4
-        PROFILE.append((f"wgrad_kernel<{_tname(dtype)}, {t}, {t}, {loader}>", 2.0 * M * N * Kw, e0, e1,
+        PROFILE.append((f"wgrad_kernel<{_tname(dtype)}, {t}, {t2}, {loader}>", 2.0 * M * N * Kw, e0, e1,
                         (M * N + B * H * W * C) * es + N * Kw * 4))
 
 
