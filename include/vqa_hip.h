@@ -36,7 +36,7 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw, i
               int C, int Ho, int Wo, int R, int S, int stride, int pad, hipStream_t stream);
 int vqa_pack_rows(int dtype, const float* in, void* out, int N, int K, int Kp, hipStream_t stream);          /* cast + row pad   */
 int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int T, int C, int ldo, int col0, int flip, hipStream_t stream); /* out[c][col0+t*N+n] = in[n][flip?T-1-t:t][c] */
-int vqa_pack_transpose_batch(int dtype, const float* flat, void* out, const long long* desc, int nd, int total_blocks, hipStream_t stream); /* nd pieces, device table desc[nd][10] = {src_off, dst_off, N, T, C, ldo, col0, flip, blk0, 0}: every data-gradient operand of a step in one launch */
+int vqa_pack_transpose_batch(int dtype, const float* flat, void* out, const long long* desc, int nd, int total_blocks, hipStream_t stream); /* nd pieces, device table desc[nd][10] = {src_off, dst_off, N, T, C, ldo, col0, flip, blk0, 0}, blk0 = running sum of T*ceil(N/32)*ceil(C/32): every data-gradient operand of a step in one launch */
 /* Eval-mode Conv+BN folding, all convs in one launch (inference path, api/inference.py:196-323 via VQAModel.predict):
  * w'[n][k] = w[n][k]*gamma[n]/sqrt(running_var[n]+eps) cast to dtype, b'[n] = beta[n] - running_mean[n]*scale[n].
  * desc: device table [nd][10] int64 {w_off, gamma_off, beta_off (floats from flat), running_mean ptr, running_var ptr, N, K,

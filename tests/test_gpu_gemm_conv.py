@@ -238,3 +238,30 @@ def test_conv3x3_c64_patch_kernels(case):
     K.wgrad3x3_c64(nhwc(x), nhwc(dy), dw, B, H, W)
     torch.cuda.synchronize()
     assert _relerr(dw.cpu(), wr.grad.permute(0, 2, 3, 1).reshape(64, 576)) < 3e-3
+
+
+def test_pack_transpose_batch_matches_single_launches():
+    """The tiled one-launch weight transpose (begin_step) against the per-weight kernel, including taps, flip, a column
+    offset inside a wider row, and dimensions that are not multiples of the 32x32 tile."""
+    K, L = sub("kernels"), sub("_lib")
+    g = torch.Generator().manual_seed(9)
+    pieces = [(10, 1, 40, False, 0, 0), (64, 9, 64, False, 0, 0), (128, 9, 64, True, 0, 0), (96, 1, 24, False, 9 * 96, 1), (8, 9, 16, False, 0, 0)]
+    for dtype in (torch.bfloat16, torch.float32):
+        flat_parts, rows, refs, src, dst, blk = [], [], [], 0, 0, 0
+        for n, tt, c, flip, col0, wide in pieces:
+            w = torch.randn(n, tt, c, generator=g)
+            flat_parts.append(w.reshape(-1))
+            ld = tt * n + (col0 if wide else 0)
+            ref = torch.full((c, ld), 0.0, device=DEV, dtype=dtype)
+            K.pack_transpose(w.to(DEV), dtype, out=ref, ldo=ld, col0=col0, flip=flip)
+            rows.append([src, dst, n, tt, c, ld, col0, int(flip), blk, 0])
+            refs.append((dst, c, ld, col0, tt * n, ref))
+            src += n * tt * c; dst += (c * ld + 7) // 8 * 8; blk += tt * ((n + 31) // 32) * ((c + 31) // 32)
+        flat = torch.cat(flat_parts).to(DEV)
+        out = torch.zeros(dst, device=DEV, dtype=dtype)
+        table = torch.tensor(rows, dtype=torch.int64).to(DEV)
+        L.call("vqa_pack_transpose_batch", int(dtype == torch.bfloat16), flat.data_ptr(), out.data_ptr(), table.data_ptr(), len(rows), blk)
+        torch.cuda.synchronize()
+        for d0, c, ld, col0, width, ref in refs:
+            got = out[d0: d0 + c * ld].view(c, ld)
+            assert torch.equal(got[:, col0: col0 + width], ref[:, col0: col0 + width])

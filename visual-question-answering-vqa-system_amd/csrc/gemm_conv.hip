@@ -690,9 +690,12 @@ __global__ void pack_transpose_kernel(const float* __restrict__ in, T* __restric
 }
 
 // All data-gradient operands of one step in ONE launch.  desc[d] = {src_off, dst_off, N, TT, C, ldo, col0, flip, blk0, 0} (int64):
-// piece d covers workgroups blk0[d] .. blk0[d+1]-1 and is packed exactly like pack_transpose_kernel.
+// piece d covers workgroups blk0[d] .. blk0[d+1]-1; out[c][col0 + t*N + n] = in[n][flip ? TT-1-t : t][c] as in pack_transpose_kernel.
 template <typename T>
-__global__ void pack_transpose_batch_kernel(const float* __restrict__ flat, T* __restrict__ outbase, const long long* __restrict__ desc, int nd) {
+__global__ __launch_bounds__(256) void pack_transpose_batch_kernel(const float* __restrict__ flat, T* __restrict__ outbase,
+                                                                   const long long* __restrict__ desc, int nd) {
+  // One workgroup = one 32 (n) x 32 (c) tile of one tap: rows are read along c (coalesced), transposed through LDS and written
+  // along n (coalesced).  blocks of piece d: TT * ceil(N/32) * ceil(C/32), tap-major.
   int lo = 0, hi = nd - 1;                               // last piece whose blk0 <= blockIdx.x (uniform -> scalar loads)
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -702,11 +705,24 @@ __global__ void pack_transpose_batch_kernel(const float* __restrict__ flat, T* _
   const float* in = flat + d[0];
   T* out = outbase + d[1];
   const int N = (int)d[2], TT = (int)d[3], C = (int)d[4], ldo = (int)d[5], col0 = (int)d[6], flip = (int)d[7];
-  size_t i = (size_t)(blockIdx.x - (int)d[8]) * blockDim.x + threadIdx.x;
-  if (i >= (size_t)N * TT * C) return;
-  int n = (int)(i % N); size_t r = i / N; int t = (int)(r % TT); int c = (int)(r / TT);
+  const int tn = (N + 31) >> 5, tc = (C + 31) >> 5;
+  int rel = blockIdx.x - (int)d[8];
+  const int t = rel / (tn * tc); rel -= t * tn * tc;
+  const int n0 = (rel / tc) << 5, c0 = (rel % tc) << 5;
   const int ts = flip ? TT - 1 - t : t;
-  out[(size_t)c * ldo + col0 + t * N + n] = from_f<T>(in[((size_t)n * TT + ts) * C + c]);
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 8 rows per pass
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, c = c0 + tx;
+    tile[r][tx] = (n < N && c < C) ? in[((size_t)n * TT + ts) * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, n = n0 + tx;
+    if (c < C && n < N) out[(size_t)c * ldo + col0 + t * N + n] = from_f<T>(tile[tx][r]);
+  }
 }
 
 // Eval-mode Conv+BatchNorm folding for every conv of the network in ONE launch:
@@ -984,7 +1000,7 @@ int vqa_fold_bn_batch(int dtype, const float* flat, void* wout, float* bout, con
 
 // Batched form of vqa_pack_transpose: nd pieces described by a DEVICE table desc [nd][10] int64
 // {src_off (floats from flat), dst_off (elements from out), N, TT, C, ldo, col0, flip, blk0, 0}; blk0 = running sum of
-// ceil(N*TT*C / 256) and total_blocks its final value.  The caller guarantees the pieces stay inside flat / out.
+// TT * ceil(N/32) * ceil(C/32) (one workgroup per 32x32 tile of a tap) and total_blocks its final value.  The caller guarantees the pieces stay inside flat / out.
 int vqa_pack_transpose_batch(int dtype, const float* flat, void* out, const long long* desc, int nd, int total_blocks, hipStream_t st) {
   if (!flat || !out || !desc || nd <= 0 || total_blocks <= 0) return VQA_EARG;
   if (dtype) hipLaunchKernelGGL(pack_transpose_batch_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, flat, (bf16_t*)out, desc, nd);

@@ -82,7 +82,7 @@ class HipEngine:
             for key, (pieces, rows, ld) in self._wt_plan.items():
                 for off, n, tt, c, col0, flip in pieces:
                     rowsd.append([off, dst, n, tt, c, ld, col0, int(flip), blk, 0])
-                    blk += (n * tt * c + 255) // 256
+                    blk += tt * ((n + 31) // 32) * ((c + 31) // 32)      # one workgroup per 32x32 tile of a tap
                 views.append((key, dst, rows, ld))
                 dst += (rows * ld + 7) // 8 * 8
             self._wt_table = (torch.tensor(rowsd, dtype=torch.int64).to(self.flat.device), views, dst, blk, len(rowsd))
