@@ -27,6 +27,7 @@ struct IGemmParams {
   // LOADER_DGRAD2 (data gradient of a stride-2 conv, rows grouped by output parity class so only valid taps are issued):
   const void* a2;                               // second source (dY of the 1x1 shortcut), same geometry as a
   unsigned a_bytes, a2_bytes, w_bytes;          // buffer extents for the hardware range check
+  int dbg;                                      // measurement switch (VQA_IGEMM_DBG): bit 0 no in-loop DMA, bit 1 no MFMA phase
   unsigned long long mul_howo, mul_wo;          // ceil(2^40 / d) for d = Ho*Wo, Wo (DGRAD2: (Ho/2)*(Wo/2), Wo/2): exact m / d for m*d < 2^40
   int ntaps[4]; int tap_koff[4][5]; int tap_dh[4][5]; int tap_dw[4][5]; int tap_src[4][5];
 };
@@ -93,9 +94,9 @@ __device__ __forceinline__ Vec16<T> load_a_stem(const float* img, const RowInfo&
 // Two shapes of the same kernel: 4 waves x (64 x 64) with BK = 64 (bf16) and, for 128-wide N tiles, 2 waves x (128 x 64) with
 // BK = 32: the larger wave tile reads 25% fewer LDS bytes per MFMA (the 64 x 64 shape keeps the LDS pipe as busy as the MFMA
 // pipe), its 64-byte rows use the swizzle c ^ ((r >> 2) & 3), and four 2-wave workgroups share a CU.
-template <typename T, int BM, int BN, int BK = GT<T>::BK> struct IGemmCfg {
+template <typename T, int BM, int BN, int BK = GT<T>::BK, int ST = 2> struct IGemmCfg {
   static constexpr int LD = BK;
-  static constexpr int TILES = 2 * (BM + BN) * LD * (int)sizeof(T);
+  static constexpr int TILES = ST * (BM + BN) * LD * (int)sizeof(T);
   static constexpr int CST = BM * (BN + GT<T>::VEC) * (int)sizeof(T);
   static constexpr int SMEM = (TILES > CST + 4096 ? TILES : CST + 4096);   // BN-statistics scratch sits right after the C staging area
 };
@@ -109,7 +110,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2>
+template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2>
 __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   // OCC waves per SIMD (2 -> <= 256 VGPRs)
   using G = GT<T>;
   constexpr int VEC = G::VEC, LD = BK;
@@ -120,10 +121,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
   static_assert(RPP % 32 == 0 && (CPR == 8 || CPR == 4) && BN <= NTHR, "staging map");
   constexpr int WN = BN / 64, WM = NW / WN, TM = BM / WM, MT = TM / 16, NT = 4;
   constexpr int AV = BM / RPP, BV = BN / RPP;
-  constexpr int SMEM = IGemmCfg<T, BM, BN, BK>::SMEM;
+  constexpr int SMEM = IGemmCfg<T, BM, BN, BK, ST>::SMEM;
+  static_assert(ST == 2 || (ST == 3 && LOADER != LOADER_STEM), "ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* As = reinterpret_cast<T*>(smem);
-  T* Bs = As + 2 * BM * LD;
+  T* Bs = As + ST * BM * LD;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA destinations and tile offsets stay in SGPRs
   const int wm = wave / WN, wn = wave % WN;
@@ -237,8 +239,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
     const int kw = (LOADER == LOADER_DGRAD2) ? p.tap_koff[cls][tap] + cc * BK : kt * BK;
 #if defined(__HIP_DEVICE_COMPILE__)     // device pass only: the host pass cannot form LDS (address_space 3) pointers
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    char* abase = smem + ((size_t)((kt & 1) * BM + wave * RPI) * LD) * sizeof(T);
-    char* bbase = smem + ((size_t)(2 * BM + (kt & 1) * BN + wave * RPI) * LD) * sizeof(T);
+    const int slot = (ST == 2) ? (kt & 1) : (kt % ST);
+    char* abase = smem + ((size_t)(slot * BM + wave * RPI) * LD) * sizeof(T);
+    char* bbase = smem + ((size_t)(ST * BM + slot * BN + wave * RPI) * LD) * sizeof(T);
     if (a_tail) {                                     // Linear whose K is not a multiple of BK: mask the chunks past the row end
       const bool cok = (cc * BK + lvec * VEC) < p.C;
 #pragma unroll
@@ -312,13 +315,34 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
     }
   };
 
-  if (nk > 0) { gload(0); if (!DMA) sstore(0); }
-  __syncthreads();                       // (with LDS-DMA in flight the barrier's fence waits vmcnt(0): tile 0 has landed)
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload(kt + 1);      // DMA: straight into the other LDS buffer, all waves left it at the last barrier
-    compute(kt & 1);
-    if (!DMA && kt + 1 < nk) sstore((kt + 1) & 1);
-    __syncthreads();
+  // p.dbg (VQA_IGEMM_DBG, measurement only): bit 0 = no DMA inside the K loop, bit 1 = no MFMA / LDS-read phase
+  const bool dbg_nodma = p.dbg & 1, dbg_nomma = p.dbg & 2;
+  if constexpr (ST == 3) {
+    // 3-slot ring, two K steps of DMA in flight: the barrier that ends step kt only waits for tile kt+1 (counted vmcnt: the
+    // AV + BV LDS-DMA instructions of tile kt+2 may still be outstanding), so a tile has two compute phases to land.
+    if (nk > 0) gload(0);
+    if (nk > 1) {
+      gload(1);
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(AV + BV) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = (kt + 2 < nk) && !dbg_nodma;
+      if (more) gload(kt + 2);           // slot (kt+2)%3 == (kt-1)%3: every wave finished reading it before the last barrier
+      if (!dbg_nomma) compute(kt % 3);
+      if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(AV + BV) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  } else {
+    if (nk > 0) { gload(0); if (!DMA) sstore(0); }
+    __syncthreads();                     // (with LDS-DMA in flight the barrier's fence waits vmcnt(0): tile 0 has landed)
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk && !dbg_nodma) gload(kt + 1);   // DMA: straight into the other LDS buffer, all waves left it at the last barrier
+      if (!dbg_nomma) compute(kt & 1);
+      if (!DMA && kt + 1 < nk) sstore((kt + 1) & 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue.  The MFMA operands were swapped, so a lane holds 4 CONSECUTIVE COLUMNS of one row:
@@ -355,7 +379,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
         }
   }
   // ---- BatchNorm partial statistics (sum, sum of squares per output channel of this M tile) ----
-  float* red = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN, BK>::CST);   // [WM][BN][2], after the C staging area (tiles are dead by now)
+  float* red = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN, BK, ST>::CST);   // [WM][BN][2], after the C staging area (tiles are dead by now)
   if (p.stats) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -758,23 +782,25 @@ __global__ void fold_bn_batch_kernel(const float* __restrict__ flat, T* __restri
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2>
+template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2>
 static int launch_igemm(const IGemmParams& p, hipStream_t st) {
-  constexpr int SMEM = IGemmCfg<T, BM, BN, BK>::SMEM;
+  constexpr int SMEM = IGemmCfg<T, BM, BN, BK, ST>::SMEM;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC>), dim3(tiles), dim3(NW * 64), SMEM, st, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST>), dim3(tiles), dim3(NW * 64), SMEM, st, p);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }
 
 static void igemm_tile(int M, int N, int* bm, int* bn) {
+  static int bm_env = -1;
+  if (bm_env < 0) { const char* e = getenv("VQA_IGEMM_BM"); bm_env = e ? atoi(e) : 128; }
   if (N <= 64) { *bn = 64; *bm = 128; }      // (256-row tiles were measured slower for the 64-channel layers)
-  else { *bn = 128; *bm = 128; }
+  else { *bn = 128; *bm = (bm_env >= 256 && M >= 256 * 256) ? 256 : 128; }   // 256 / 257: opt-in 8-wave 256x128 tile (2 / 3 slots)
   long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
   if (tiles < 384) { *bm = 64; *bn = 64; }
 }
@@ -783,6 +809,12 @@ template <typename T>
 static int igemm_dispatch(const IGemmParams& p, int loader, hipStream_t st) {
   int bm, bn; igemm_tile(p.M, p.N, &bm, &bn);
   if (loader == LOADER_STEM) return launch_igemm<T, 128, 64, LOADER_STEM>(p, st);
+  if (bm == 256 && bn == 128) {
+    if constexpr (sizeof(T) == 2) {
+      static const int ring3 = getenv("VQA_IGEMM_BM") && atoi(getenv("VQA_IGEMM_BM")) == 257;
+      return ring3 ? launch_igemm<T, 256, 128, LOADER_NHWC, 8, 64, 2, 3>(p, st) : launch_igemm<T, 256, 128, LOADER_NHWC, 8, 64, 2, 2>(p, st);
+    } else return launch_igemm<T, 128, 128, LOADER_NHWC>(p, st);
+  }
   if (bm == 128 && bn == 128) {
     if constexpr (sizeof(T) == 2) {
       // 2 waves x (128 x 64), BK = 32: needs whole 64-wide K steps (the host rounds Kp to 64) -> any conv / Linear without a K tail
@@ -855,6 +887,8 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
     p.mul_wo = (one + (unsigned long long)Wo - 1) / (unsigned long long)Wo;
   }
   for (int c = 0; c < 4; ++c) p.ntaps[c] = 0;
+  static const int dbg_env = getenv("VQA_IGEMM_DBG") ? atoi(getenv("VQA_IGEMM_DBG")) : 0;
+  p.dbg = dbg_env;
   return dtype ? igemm_dispatch<bf16_t>(p, loader, st) : igemm_dispatch<float>(p, loader, st);
 }
 
@@ -869,7 +903,7 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
   p.a = dy; p.a2 = dyd; p.w = wt; p.out = out; p.bias = nullptr; p.addend = nullptr; p.addmask = nullptr; p.stats = nullptr;
   p.N = N; p.Kw = R * R * C + (dyd ? C : 0); p.Kp = p.Kw; p.M = B * Ho * Wo;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = R; p.stride = 2; p.pad = pad;
-  p.transposed = 1; p.relu = 0; p.drop_p = 0.f; p.drop_seed = 0;
+  p.transposed = 1; p.relu = 0; p.drop_p = 0.f; p.drop_seed = 0; p.dbg = 0;
   {
     const size_t es = dtype ? 2 : 4;
     const size_t ab = (size_t)B * H * W * C * es, wb = (size_t)N * p.Kw * es;
