@@ -94,9 +94,9 @@ __device__ __forceinline__ Vec16<T> load_a_stem(const float* img, const RowInfo&
 // Two shapes of the same kernel: 4 waves x (64 x 64) with BK = 64 (bf16) and, for 128-wide N tiles, 2 waves x (128 x 64) with
 // BK = 32: the larger wave tile reads 25% fewer LDS bytes per MFMA (the 64 x 64 shape keeps the LDS pipe as busy as the MFMA
 // pipe), its 64-byte rows use the swizzle c ^ ((r >> 2) & 3), and four 2-wave workgroups share a CU.
-template <typename T, int BM, int BN, int BK = GT<T>::BK, int ST = 2> struct IGemmCfg {
+template <typename T, int BM, int BN, int BK = GT<T>::BK, int ST = 2, int WIN = 0> struct IGemmCfg {
   static constexpr int LD = BK;
-  static constexpr int TILES = ST * (BM + BN) * LD * (int)sizeof(T);
+  static constexpr int TILES = ST * (BM + 8 * WIN + BN) * LD * (int)sizeof(T);   // WIN: the A buffers hold a window of BM + 8 pixels
   static constexpr int CST = BM * (BN + GT<T>::VEC) * (int)sizeof(T);
   static constexpr int SMEM = (TILES > CST + 4096 ? TILES : CST + 4096);   // BN-statistics scratch sits right after the C staging area
 };
@@ -110,7 +110,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2>
+template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2, int WIN = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   // OCC waves per SIMD (2 -> <= 256 VGPRs)
   using G = GT<T>;
   constexpr int VEC = G::VEC, LD = BK;
@@ -121,8 +121,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
   static_assert(RPP % 32 == 0 && (CPR == 8 || CPR == 4) && BN <= NTHR, "staging map");
   constexpr int WN = BN / 64, WM = NW / WN, TM = BM / WM, MT = TM / 16, NT = 4;
   constexpr int AV = BM / RPP, BV = BN / RPP;
-  constexpr int SMEM = IGemmCfg<T, BM, BN, BK, ST>::SMEM;
+  constexpr int SMEM = IGemmCfg<T, BM, BN, BK, ST, WIN>::SMEM;
   static_assert(ST == 2 || (ST == 3 && LOADER != LOADER_STEM), "ring depth");
+  static_assert(!WIN || (LOADER == LOADER_NHWC && ST == 2 && sizeof(T) == 2 && CPR == 8), "window loader: bf16 NHWC, double buffered");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* As = reinterpret_cast<T*>(smem);
   T* Bs = As + ST * BM * LD;
@@ -168,6 +169,121 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (WIN) {
+    // ---- window loader (stride-1 3x3 pad-1 conv and its data gradient; H == Ho, W == Wo).  Tap (r, s) of output pixel m reads
+    //      the flattened input pixel q = m + dr(r)*W + (ds(s) - 1) (dr = r-1 / 1-r, ds = s / 2-s for forward / transposed), so the
+    //      three taps of one filter row read ONE window of BM + 2 consecutive pixels: it is staged once per (r, channel chunk) and
+    //      sub-step ds reads its fragments at row offset ds.  Positions whose (oh+dr, ow+ds-1) fall outside the image are zeroed
+    //      at fragment level with per-lane bit masks (the wrapped pixel q is real data there).  A pieces per wave and K step:
+    //      4/3 (+1/3 tail) instead of 4 -- the LDS-DMA issue cost is what bounds this kernel.
+    constexpr int AW = BM + 8;
+    constexpr int OOB = (int)0x80000000;
+    constexpr int ES = (int)sizeof(T);
+    T* Aw = reinterpret_cast<T*>(smem);                  // [2][AW][LD]
+    T* Bw = Aw + 2 * AW * LD;                            // [2][BN][LD]
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+    const int cpb = p.C / BK, nwin = 3 * cpb, nk = 3 * nwin;
+    const int csz = p.C * ES, npix = p.B * p.H * p.W;
+    const bool trm = p.transposed != 0;
+    const int lvec = vec ^ swz;
+    unsigned vmask[MT];                                  // bit r*3 + ds: tap row r, window offset ds is inside the image
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * TM + i * 16 + (lane & 15);
+      unsigned mk = 0;
+      if (m < p.M) {
+        const int b = fast_div(m, p.mul_howo), rem = m - b * (p.Ho * p.Wo);
+        const int oh = fast_div(rem, p.mul_wo), ow = rem - oh * p.Wo;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int dr = trm ? 1 - r : r - 1;
+          const bool rok = (unsigned)(oh + dr) < (unsigned)p.H;
+#pragma unroll
+          for (int ds = 0; ds < 3; ++ds)
+            if (rok && (unsigned)(ow + ds - 1) < (unsigned)p.W) mk |= 1u << (r * 3 + ds);
+        }
+      }
+      vmask[i] = mk;
+    }
+    int boff[BV], aoff[AV], aoff_tail = OOB;
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int n = n0 + rbase + RPP * i;
+      boff[i] = (n < p.N) ? (n * p.Kw + lvec * VEC) * ES : OOB;
+    }
+    auto set_row = [&](int r) {                          // vector offsets of this thread's window rows for filter row r
+      const int qb = m0 - 1 + (trm ? 1 - r : r - 1) * p.W;
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        const int q = qb + rbase + RPP * i;
+        aoff[i] = ((unsigned)q < (unsigned)npix) ? q * csz + lvec * VEC * ES : OOB;
+      }
+      const int qt = qb + BM + (lane >> 3);              // the 8 tail rows, staged by wave 0 (rbase == lane >> 3 there)
+      aoff_tail = ((unsigned)qt < (unsigned)npix) ? qt * csz + lvec * VEC * ES : OOB;
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto load_a = [&](int w, int cc) {                   // window w -> A buffer w & 1
+      char* abase = smem + ((size_t)((w & 1) * AW + wave * RPI) * LD) * ES;
+#pragma unroll
+      for (int i = 0; i < AV; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(abase + i * RPP * LD * ES), 16, aoff[i], cc * BK * ES, 0, 0);
+      if (wave == 0)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(smem + ((size_t)((w & 1) * AW + BM) * LD) * ES), 16, aoff_tail, cc * BK * ES, 0, 0);
+    };
+    auto load_b = [&](int kt, int r, int cc, int j) {    // K step kt = 3*w + j -> B buffer kt & 1
+      const int s_ = trm ? 2 - j : j;
+      const int kw = ((r * 3 + s_) * p.C + cc * BK) * ES;
+      char* bbase = smem + ((size_t)(2 * AW + (kt & 1) * BN + wave * RPI) * LD) * ES;
+#pragma unroll
+      for (int i = 0; i < BV; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(bbase + i * RPP * LD * ES), 16, boff[i], kw, 0, 0);
+    };
+#else
+    auto load_a = [&](int, int) {};
+    auto load_b = [&](int, int, int, int) {};
+#endif
+    auto compute_w = [&](int kt, int w, int r, int j) {
+      const T* Ab = Aw + ((w & 1) * AW + wm * TM + (lane & 15) + j) * LD;
+      const T* Bb = Bw + ((kt & 1) * BN + wn * 64 + (lane & 15)) * LD;
+      const int rsa = ((lane & 15) + j) & 7, rsb = lane & 7;
+      const unsigned bit = 1u << (r * 3 + j);
+#pragma unroll
+      for (int kk = 0; kk < BK / G::MK; ++kk) {
+        bf16x8 af[MT], bfv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 16 * LD + (((kk * 4 + (lane >> 4)) ^ rsa) * 8));
+          if (!(vmask[i] & bit)) af[i] = bf16x8{};
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < NT; ++j2) bfv[j2] = *reinterpret_cast<const bf16x8*>(Bb + j2 * 16 * LD + (((kk * 4 + (lane >> 4)) ^ rsb) * 8));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j2 = 0; j2 < NT; ++j2)
+            acc[i][j2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[j2], af[i], acc[i][j2], 0, 0, 0);   // operands swapped: C^T
+      }
+    };
+    set_row(0); load_a(0, 0); load_b(0, 0, 0, 0);
+    __syncthreads();
+    int w = 0, r = 0, cc = 0, j = 0;                     // cursor of the CURRENT step: window w = r*cpb + cc, sub-step j
+    for (int kt = 0; kt < nk; ++kt) {
+      // next step's (w, r, cc, j)
+      int nj = j + 1, ncc = cc, nr = r, nw_ = w;
+      if (nj == 3) { nj = 0; ++nw_; if (++ncc == cpb) { ncc = 0; ++nr; } }
+      if (kt + 1 < nk) load_b(kt + 1, nr, ncc, nj);
+      if (j == 0 && w + 1 < nwin) {                      // stage the NEXT window while this one serves its three taps
+        int r2 = r, cc2 = cc + 1;
+        if (cc2 == cpb) { cc2 = 0; ++r2; set_row(r2); }
+        load_a(w + 1, cc2);
+      }
+      compute_w(kt, w, r, j);
+      __syncthreads();
+      j = nj; cc = ncc; r = nr; w = nw_;
+    }
+  } else {
   Vec16<T> ra[AV], rb[BV];
   const int taps = p.R * p.S;
   // K steps per tap; a Linear (1 tap) keeps all its K steps in "tap 0"
@@ -345,6 +461,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
     }
   }
 
+  }
+
   // ---- epilogue.  The MFMA operands were swapped, so a lane holds 4 CONSECUTIVE COLUMNS of one row:
   //        acc[i][j][r] = C[m = wm*TM + i*16 + (lane & 15)][n = wn*64 + j*16 + (lane >> 4)*4 + r]
   //      -> packed conversion and one 8-byte (bf16) / 16-byte (fp32) LDS store per (i, j) instead of four scalar ones.
@@ -379,7 +497,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
         }
   }
   // ---- BatchNorm partial statistics (sum, sum of squares per output channel of this M tile) ----
-  float* red = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN, BK, ST>::CST);   // [WM][BN][2], after the C staging area (tiles are dead by now)
+  float* red = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN, BK, ST, WIN>::CST);   // [WM][BN][2], after the C staging area (tiles are dead by now)
   if (p.stats) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -782,16 +900,16 @@ __global__ void fold_bn_batch_kernel(const float* __restrict__ flat, T* __restri
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2>
+template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2, int WIN = 0>
 static int launch_igemm(const IGemmParams& p, hipStream_t st) {
-  constexpr int SMEM = IGemmCfg<T, BM, BN, BK, ST>::SMEM;
+  constexpr int SMEM = IGemmCfg<T, BM, BN, BK, ST, WIN>::SMEM;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST>), dim3(tiles), dim3(NW * 64), SMEM, st, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST, WIN>), dim3(tiles), dim3(NW * 64), SMEM, st, p);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }
@@ -809,6 +927,15 @@ template <typename T>
 static int igemm_dispatch(const IGemmParams& p, int loader, hipStream_t st) {
   int bm, bn; igemm_tile(p.M, p.N, &bm, &bn);
   if (loader == LOADER_STEM) return launch_igemm<T, 128, 64, LOADER_STEM>(p, st);
+  if constexpr (sizeof(T) == 2) {
+    // stride-1 3x3 pad-1 convs (forward and data gradient): one staged pixel window serves the three taps of a filter row
+    static const int win_env = getenv("VQA_IGEMM_WIN") ? atoi(getenv("VQA_IGEMM_WIN")) : 1;
+    if (win_env && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.H == p.Ho && p.W == p.Wo && p.C % 64 == 0 && bm == 128 &&
+        (long)p.B * p.H * p.W == (long)p.M) {
+      if (bn == 128) return launch_igemm<T, 128, 128, LOADER_NHWC, 4, 64, 2, 2, 1>(p, st);
+      if (bn == 64) return launch_igemm<T, 128, 64, LOADER_NHWC, 4, 64, 2, 2, 1>(p, st);
+    }
+  }
   if (bm == 256 && bn == 128) {
     if constexpr (sizeof(T) == 2) {
       static const int ring3 = getenv("VQA_IGEMM_BM") && atoi(getenv("VQA_IGEMM_BM")) == 257;
