@@ -1111,7 +1111,10 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
   static const int nostage = getenv("VQA_WGRAD_NOSTAGE") ? 1 : 0;
   p.dbg_noatomic = nostage;      // 1: flush straight from the accumulators (A/B switch)
   long nsplit = (target + tiles - 1) / tiles;                 // aim for ~target workgroups
-  long maxsplit = (M + 255) / 256;                           // at least 256 rows per split
+  // every split flushes a whole fp32 tile with atomics: token-side GEMMs (M ~ 10^4) are flush-bound unless a split keeps
+  // >= ~1000 rows (16 K steps) of work
+  static const long minchunk = getenv("VQA_WGRAD_MINCHUNK") ? atol(getenv("VQA_WGRAD_MINCHUNK")) : 1024;
+  long maxsplit = (M + minchunk - 1) / minchunk;
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
   int chunk = (int)((M + nsplit - 1) / nsplit);
