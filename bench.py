@@ -147,9 +147,12 @@ def main():
         traffic = None                      # HBM bytes per launch from rocprofv3 PMC passes (tools/hbm_traffic.py), if recorded
         tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(tpath) and args.batch == 512 and args.dtype == "bf16":
-            for kname, v in json.load(open(tpath))["kernels"].items():
-                if name.rstrip('>') in kname:      # the PROFILE name is a prefix of the full template instantiation
-                    traffic = round(v["hbm_bytes_per_launch"])
+            tb = tn = 0.0                           # the PROFILE name is a prefix of the full template instantiation(s):
+            for kname, v in json.load(open(tpath))["kernels"].items():      # launch-weighted mean over all of them
+                if name.rstrip('>') in kname:
+                    tb += v["hbm_bytes_per_launch"] * v["launches"]; tn += v["launches"]
+            if tn:
+                traffic = round(tb / tn)
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                 "frac": round(ach / PEAK[args.dtype], 4), "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE)",
                 "algorithmic_bytes_per_launch": round(nb / n), "launches_per_step": n,
