@@ -95,7 +95,8 @@ def param_shapes(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
                 (p + ".ffn.fc2.weight", (d, f), "default_w"), (p + ".ffn.fc2.bias", (d,), "default_b"),
                 (p + ".norm2.weight", (d,), "ones"), (p + ".norm2.bias", (d,), "zeros")]
     out += [("text_encoder.final_norm.weight", (d,), "ones"), ("text_encoder.final_norm.bias", (d,), "zeros")]
-    out.append(("fusion.image_projector.position_embedding", (1, 49, d), "posemb"))
+    # the reference hard-codes 49 positions (models/fusion.py:66); "num_image_tokens" is this repo's extension for the 384x384 stress shape
+    out.append(("fusion.image_projector.position_embedding", (1, cfg.get("num_image_tokens", 49), d), "posemb"))
     out += [("fusion.image_projector.projection.0.weight", (d, 512), "default_w"),
             ("fusion.image_projector.projection.0.bias", (d,), "default_b"),
             ("fusion.image_projector.projection.1.weight", (d,), "ones"),

@@ -50,3 +50,49 @@ def test_variant_train_step_matches_oracle(tag, kw, B, isz, L, use_mask, trainin
     ref = np.array([float(tr.sd[n].grad.double().norm()) for n in names])
     rel = np.abs(got - ref) / np.maximum(ref, 1e-6 * ref.max())
     assert rel.max() < 3e-2, (tag, names[int(rel.argmax())], rel.max())
+
+
+def test_stress_shape_384px_144_tokens_matches_oracle():
+    """BASELINE configs[4] shape at a small batch: 384x384 images -> 12x12 = 144 image tokens, embed_dim 512, 8 text layers,
+    2000 answers.  The reference cannot run it (49 hard-coded positions, models/fusion.py:66), so this is ORACLE parity only
+    ("parity unpinned" against the reference): fp32 train step with dropout 0, logits / loss / per-tensor gradient norms; the
+    keys exceed the MFMA attention tile (144 > 64), so the LDS/VALU attention kernels run."""
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0, vocab_size=500, num_answers=2000, embed_dim=512, num_transformer_layers=8,
+                        num_image_tokens=144)
+    sd = O.init_state_dict(cfg, 77, jitter=True)
+    B = 2
+    images, ids, mask, answers = O.synthetic_batch(B, seed=78, image_size=384, seq_len=20, vocab=500, num_answers=2000)
+    m = pkg().load_dropin().VQAModel(**cfg, compute_dtype="fp32")
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    logits, aux = m(images.to(DEV), ids.to(DEV), mask.to(DEV), return_aux=True)
+    assert aux["cross_attention_weights"][0].shape == (B, 8, 20, 144)
+    loss = torch.nn.functional.cross_entropy(logits, answers.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    tr = O.OracleTrainer(sd, cfg)
+    lref, _ = O.vqa_forward(images, ids, mask, tr.sd, cfg, True, {})
+    loss_ref = torch.nn.functional.cross_entropy(lref, answers)
+    loss_ref.backward()
+    assert (logits.detach().cpu() - lref.detach()).abs().max().item() < 1e-3
+    assert abs(loss.item() - loss_ref.item()) < 1e-4
+    P = dict(m.named_parameters())
+    names = O.parameter_names(cfg)
+    got = np.array([float(P[n].grad.double().norm()) for n in names])
+    ref = np.array([float(tr.sd[n].grad.double().norm()) for n in names])
+    rel = np.abs(got - ref) / np.maximum(ref, 1e-6 * ref.max())
+    assert rel.max() < 3e-2, (names[int(rel.argmax())], rel.max())
+    # bf16 throughput path at the same shape: finite and close
+    mb = pkg().load_dropin().VQAModel(**cfg, compute_dtype="bf16")
+    mb.load_state_dict(sd)
+    mb = mb.to(DEV).eval()
+    with torch.no_grad():
+        lb, _ = mb(images.to(DEV), ids.to(DEV), mask.to(DEV))
+        le, _ = O.vqa_forward(images, ids, mask, sd, cfg, False, {})       # oracle eval forward on the ORIGINAL buffers
+    err = (lb.cpu() - le).abs().max().item() / max(1.0, le.abs().max().item())
+    assert torch.isfinite(lb).all() and err < 5e-2, err
+    # 49-position model fed a 384x384 image fails like the reference (shape error), not silently
+    m49 = pkg().load_dropin().VQAModel(**{k: v for k, v in cfg.items() if k != "num_image_tokens"}, compute_dtype="fp32").to(DEV).eval()
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m49(images.to(DEV), ids.to(DEV), mask.to(DEV))

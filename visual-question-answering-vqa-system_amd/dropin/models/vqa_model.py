@@ -92,7 +92,10 @@ class VQAModel(nn.Module):
                  use_se_attention: bool = True, use_spatial_attention: bool = True, se_reduction: int = 16,
                  num_transformer_layers: int = 4, num_attention_heads: int = 8, ffn_hidden_dim: int = 1024,
                  max_question_length: int = 20, num_cross_layers: int = 2, use_gating: bool = True,
-                 dropout: float = 0.1, answer_dropout: float = 0.3, compute_dtype: Optional[str] = None, seed: Optional[int] = None):
+                 dropout: float = 0.1, answer_dropout: float = 0.3, compute_dtype: Optional[str] = None, seed: Optional[int] = None,
+                 num_image_tokens: int = 49):
+        # compute_dtype / seed / num_image_tokens are extensions; the reference hard-codes 49 image positions (models/fusion.py:66),
+        # num_image_tokens = 144 is the 384x384 stress shape of BASELINE configs[4]
         super().__init__()
         assert embed_dim % num_attention_heads == 0, \
             f"embed_dim ({embed_dim}) must be divisible by num_heads ({num_attention_heads})"
@@ -105,6 +108,8 @@ class VQAModel(nn.Module):
                            num_attention_heads=num_attention_heads, ffn_hidden_dim=ffn_hidden_dim,
                            max_question_length=max_question_length, num_cross_layers=num_cross_layers,
                            use_gating=use_gating, dropout=dropout, answer_dropout=answer_dropout)
+        if num_image_tokens != 49:
+            self.config["num_image_tokens"] = int(num_image_tokens)
         cd = (compute_dtype or os.environ.get("VQA_HIP_DTYPE", "bf16")).lower()
         self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[cd]
         self._entries = lay.build_entries(self.config)

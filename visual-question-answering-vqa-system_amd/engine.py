@@ -421,6 +421,8 @@ class HipEngine:
         pz = self._lin(feat, pj + ".0.weight", pj + ".0.bias")
         sdp = self._seed()
         posemb = self.P("fusion.image_projector.position_embedding")
+        if ntok * d > posemb.numel():            # the reference fails the same way (broadcast error at models/fusion.py:110)
+            raise RuntimeError(f"{ntok} image tokens but position_embedding holds {posemb.numel() // d} (num_image_tokens)")
         img, img_st = self._ln(pz, pj + ".1", p=pdrop, seed=sdp, addrow=posemb, period=ntok)
         tape["proj"] = dict(feat=feat, pz=pz, st=img_st, seed=sdp, p=pdrop, ntok=ntok)
         q = enc

@@ -92,7 +92,7 @@ def build_entries(cfg: dict) -> List[Entry]:
         P(p + ".ffn.fc2.weight", (d, f), "linear_w"); P(p + ".ffn.fc2.bias", (d,), "linear_b")
         P(p + ".norm2.weight", (d,), "ones"); P(p + ".norm2.bias", (d,), "zeros")
     P("text_encoder.final_norm.weight", (d,), "ones"); P("text_encoder.final_norm.bias", (d,), "zeros")
-    P("fusion.image_projector.position_embedding", (1, 49, d), "posemb")
+    P("fusion.image_projector.position_embedding", (1, cfg.get("num_image_tokens", 49), d), "posemb")   # 49: models/fusion.py:66
     P("fusion.image_projector.projection.0.weight", (d, 512), "linear_w")
     P("fusion.image_projector.projection.0.bias", (d,), "linear_b")
     P("fusion.image_projector.projection.1.weight", (d,), "ones"); P("fusion.image_projector.projection.1.bias", (d,), "zeros")
