@@ -70,6 +70,13 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
 }
+// Fast form for tensors below 2^32 elements (every tensor of this model): the seed-only half of the hash is computed once per
+// kernel (drop_key) and each element costs ONE mix32 instead of two; bit-identical to drop_keep for idx < 2^32.
+__device__ __forceinline__ uint32_t drop_key(uint64_t seed) { return mix32((uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9E3779B9u; }
+__device__ __forceinline__ bool drop_keep32(uint32_t key, uint32_t idx, float p) {
+  const uint32_t h = mix32(idx ^ key);
+  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
   uint32_t h = mix32((uint32_t)idx ^ mix32((uint32_t)(idx >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9E3779B9u);
   return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;

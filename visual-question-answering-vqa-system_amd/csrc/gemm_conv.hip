@@ -485,6 +485,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
   }
   if (p.drop_p > 0.f) {
     const float ks = 1.f / (1.f - p.drop_p);
+    const uint32_t dkey = drop_key(p.drop_seed);          // M*N < 2^32 (checked by the host entry)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
         for (int r = 0; r < 4; ++r) {
           const size_t m = (size_t)(m0 + wm * TM + i * 16 + lm);
           const int n = n0 + wn * 64 + j * 16 + lq * 4 + r;
-          acc[i][j][r] = drop_keep(p.drop_seed, m * p.N + n, p.drop_p) ? acc[i][j][r] * ks : 0.f;
+          acc[i][j][r] = drop_keep32(dkey, (uint32_t)(m * p.N + n), p.drop_p) ? acc[i][j][r] * ks : 0.f;
         }
   }
   // ---- BatchNorm partial statistics (sum, sum of squares per output channel of this M tile) ----
@@ -995,6 +996,7 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
     if (Kw % BK || N != 64 || C != 3 || R != 7 || S != 7) return VQA_EARG;
   }
   if ((long)M != (long)B * Ho * Wo) return VQA_EARG;
+  if (drop_p > 0.f && (unsigned long long)M * (unsigned long long)N >= (1ull << 32)) return VQA_EARG;   // 32-bit dropout counter
   IGemmParams p;
   p.a = a; p.w = w; p.out = out; p.bias = bias; p.addend = addend; p.addmask = addmask; p.stats = stats;
   p.M = M; p.N = N; p.Kw = Kw; p.Kp = (Kw + BK - 1) / BK * BK;

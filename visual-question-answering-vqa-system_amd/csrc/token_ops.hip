@@ -19,7 +19,7 @@ __global__ void embed_fwd_kernel(const long long* __restrict__ ids, const float*
   long long id = ids[row];
   float v = (id >= 0 && id < V) ? emb[(size_t)id * D + d] * scale : 0.f;
   v += pe[(size_t)l * D + d];
-  if (p > 0.f) v = drop_keep(seed, i, p) ? v / (1.f - p) : 0.f;
+  if (p > 0.f) v = drop_keep32(drop_key(seed), (uint32_t)(i), p) ? v / (1.f - p) : 0.f;
   out[i] = from_f<T>(v);
 }
 template <typename T>
@@ -31,7 +31,7 @@ __global__ void embed_bwd_kernel(const long long* __restrict__ ids, const T* __r
   const long long id = ids[row];
   if (id <= 0 || id >= V) return;                       // padding_idx = 0 receives no gradient
   float g = to_f<T>(dout[i]) * scale;
-  if (p > 0.f) g = drop_keep(seed, i, p) ? g / (1.f - p) : 0.f;
+  if (p > 0.f) g = drop_keep32(drop_key(seed), (uint32_t)(i), p) ? g / (1.f - p) : 0.f;
   atomicAdd(demb + (size_t)id * D + d, g);
 }
 
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     if (lane == 0 && stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
     for (int c = lane; c < D; c += 64) {
       float y = (to_f<T>(xr[c]) - mean) * rstd * gamma[c] + beta[c];
-      if (p > 0.f) y = drop_keep(seed, (uint64_t)row * D + c, p) ? y / (1.f - p) : 0.f;
+      if (p > 0.f) y = drop_keep32(drop_key(seed), (uint32_t)((uint64_t)row * D + c), p) ? y / (1.f - p) : 0.f;
       if (addrow) y += addrow[(size_t)(row % period) * D + c];
       out[(size_t)row * D + c] = from_f<T>(y);
     }
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         const size_t o = (size_t)row * D + c;
         float g = to_f<T>(dout[o]);
         if (dadd) atomicAdd(dadd + (size_t)(row % period) * D + c, g);
-        if (p > 0.f) g = drop_keep(seed, o, p) ? g / (1.f - p) : 0.f;
+        if (p > 0.f) g = drop_keep32(drop_key(seed), (uint32_t)(o), p) ? g / (1.f - p) : 0.f;
         const float h = (to_f<T>(x[o]) - mean) * rstd;
         gv[t] = g; xh[t] = h;
         ag[t] += g * h; ab[t] += g;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512) void layernorm_bwd_bf16v_kernel(const bf16_t* 
     for (int t = 0; t < 8; ++t) {
       float g = dv.get(t);
       if (dadd && act) atomicAdd(dadd + (size_t)(row % period) * D + c0 + t, g);
-      if (p > 0.f) g = drop_keep(seed, o + t, p) ? g / (1.f - p) : 0.f;
+      if (p > 0.f) g = drop_keep32(drop_key(seed), (uint32_t)(o + t), p) ? g / (1.f - p) : 0.f;
       const float h = act ? (xv.get(t) - mean) * rstd : 0.f;
       gv[t] = g; xh[t] = h;
       ag[t] += g * h; ab[t] += g;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
     for (int c = lane; c < Lk; c += 64) {
       float pr = Ps[r * ldp + c] / sum;
       pg[(size_t)r * Lk + c] = pr;
-      if (p > 0.f) pr = drop_keep(seed, ((size_t)(b * H + h) * Lq + r) * Lk + c, p) ? pr / (1.f - p) : 0.f;
+      if (p > 0.f) pr = drop_keep32(drop_key(seed), (uint32_t)(((size_t)(b * H + h) * Lq + r) * Lk + c), p) ? pr / (1.f - p) : 0.f;
       Ps[r * ldp + c] = pr;
     }
   }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ dct
     for (int c = lane; c < Lk; c += 64) {
       const float pr = pg[(size_t)r * Lk + c];
       float ks = 1.f;
-      if (p > 0.f) ks = drop_keep(seed, ((size_t)(b * H + h) * Lq + r) * Lk + c, p) ? 1.f / (1.f - p) : 0.f;
+      if (p > 0.f) ks = drop_keep32(drop_key(seed), (uint32_t)(((size_t)(b * H + h) * Lq + r) * Lk + c), p) ? 1.f / (1.f - p) : 0.f;
       float dpd = 0.f;
       for (int d = 0; d < hd; ++d) dpd += Os[r * ldh + d] * Vs[c * ldh + d];
       const float dp = dpd * ks;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
       const size_t o = (size_t)r * N + c;
       float g = to_f<T>(dout[o]);
       if (outact) { if (!(to_f<T>(outact[o]) > 0.f)) g = 0.f; else if (p > 0.f) g /= (1.f - p); }   // relu(+dropout): out>0 encodes both
-      else if (p > 0.f) g = drop_keep(seed, o, p) ? g / (1.f - p) : 0.f;
+      else if (p > 0.f) g = drop_keep32(drop_key(seed), (uint32_t)(o), p) ? g / (1.f - p) : 0.f;
       if (dz) dz[o] = from_f<T>(g);
       s += g;
     }
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
       float pr = st[t][e] * rs;
       if (sum != sum || m != m) pr = st[t][e] / sum;                       // keep NaN propagation exact (0 * inf etc.)
       Ps[r * LDP + key] = pr;
-      if (p > 0.f && r < Lq && key < Lk) pr = drop_keep(seed, prow + key, p) ? pr / (1.f - p) : 0.f;
+      if (p > 0.f && r < Lq && key < Lk) pr = drop_keep32(drop_key(seed), (uint32_t)(prow + key), p) ? pr / (1.f - p) : 0.f;
       st[t][e] = pr;
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // wave-private LDS: V tile + probabilities are visible
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
       const bool ok = r < Lq && key < Lk;
       const float pr = ok ? Ps[r * LDP + key] : 0.f;
       float ks = 1.f;
-      if (p > 0.f && ok) ks = drop_keep(seed, prow + key, p) ? keep : 0.f;
+      if (p > 0.f && ok) ks = drop_keep32(drop_key(seed), (uint32_t)(prow + key), p) ? keep : 0.f;
       const float dp = ok ? d1[t][e] * ks : 0.f;
       tq += dp * pr;
       d1[t][e] = dp;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
       const bool ok = qi < Lq && key < Lk;
       const float pr = ok ? Ps[qi * LDP + key] : 0.f;
       float ks = 1.f;
-      if (p > 0.f && ok) ks = drop_keep(seed, ((size_t)bh * Lq + qi) * Lk + key, p) ? keep : 0.f;
+      if (p > 0.f && ok) ks = drop_keep32(drop_key(seed), (uint32_t)(((size_t)bh * Lq + qi) * Lk + key), p) ? keep : 0.f;
       const float dp = ok ? d2[t][e] * ks : 0.f;
       const float tt = ok ? Ts[qi] : 0.f;
       ds2[e] = pr * (dp - tt) * inv_scale;
