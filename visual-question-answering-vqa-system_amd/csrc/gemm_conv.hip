@@ -131,8 +131,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA destinations and tile offsets stay in SGPRs
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
-  int tile_m = blockIdx.x / tiles_n;
-  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  // XCD-aware tile order: hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2), so workgroup
+  // b of XCD b%8 takes the (b/8)-th tile of that XCD's CONTIGUOUS range: neighbouring tiles (shared halo rows, the other
+  // N tiles of the same rows, the same weight tile) meet in one L2.
+  int bid = blockIdx.x;
+  if (!(p.dbg & 8)) {
+    const int nt = gridDim.x, fl = nt >> 3, rem = nt & 7, xcd = bid & 7;
+    bid = xcd * fl + (xcd < rem ? xcd : rem) + (bid >> 3);
+  }
+  int tile_m = bid / tiles_n;
+  const int tile_n = bid - tile_m * tiles_n;
   const int n0 = tile_n * BN;
   const int vec = tid % CPR, rbase = tid / CPR;
   const int swz = (CPR == 8) ? (rbase & 7) : ((rbase >> 2) & 3);      // unchanged by the + 32*i of the staging passes
