@@ -1049,7 +1049,8 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
   p.a = dy; p.a2 = dyd; p.w = wt; p.out = out; p.bias = nullptr; p.addend = nullptr; p.addmask = nullptr; p.stats = nullptr;
   p.N = N; p.Kw = R * R * C + (dyd ? C : 0); p.Kp = p.Kw; p.M = B * Ho * Wo;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = R; p.stride = 2; p.pad = pad;
-  p.transposed = 1; p.relu = 0; p.drop_p = 0.f; p.drop_seed = 0; p.dbg = 0;
+  p.transposed = 1; p.relu = 0; p.drop_p = 0.f; p.drop_seed = 0;
+  p.dbg = 8;     // plain workgroup order: the parity classes cost 1..5 taps, a contiguous tile range per XCD would unbalance the XCDs
   {
     const size_t es = dtype ? 2 : 4;
     const size_t ab = (size_t)B * H * W * C * es, wb = (size_t)N * p.Kw * es;
