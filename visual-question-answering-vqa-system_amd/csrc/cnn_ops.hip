@@ -385,16 +385,30 @@ __global__ __launch_bounds__(256) void se_pool_fc_kernel(const T* __restrict__ x
 }
 
 // out = x * rowscale[b][c] * pixscale[b][hw]   (either scale may be null)
+// A thread owns one channel vector (c0 fixed) and walks pixels with 32-bit indices; b = pix / HW is one multiply-shift
+// (mul_hw = ceil(2^40 / HW)).  (The former flat-index form spent more time in 64-bit divisions than in memory traffic.)
 template <typename T>
-__global__ void scale_kernel(const T* __restrict__ x, const float* __restrict__ chscale, const float* __restrict__ pixscale,
-                             T* __restrict__ out, size_t nvec, int HW, int C) {
+__global__ __launch_bounds__(256) void scale_kernel(const T* __restrict__ x, const float* __restrict__ chscale, const float* __restrict__ pixscale,
+                                                    T* __restrict__ out, unsigned npix, int C, unsigned long long mul_hw) {
   constexpr int VEC = Vec16<T>::N;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t e = i * VEC; const int c0 = (int)(e % C); const size_t pix = e / C; const size_t b = pix / HW;
+  const int cv = C / VEC, lanes_r = 256 / cv, c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
+  for (unsigned pix = blockIdx.x * lanes_r + myr; pix < npix; pix += gridDim.x * lanes_r) {
+    const size_t e = (size_t)pix * C + c0;
     Vec16<T> v = ldg16(x + e), o;
     const float ps = pixscale ? pixscale[pix] : 1.f;
+    if (chscale) {
+      const unsigned b = (unsigned)(((unsigned long long)pix * mul_hw) >> 40);
+      const f32x4* cs = reinterpret_cast<const f32x4*>(chscale + (size_t)b * C + c0);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o.set(j, v.get(j) * ps * (chscale ? chscale[b * C + c0 + j] : 1.f));
+      for (int q4 = 0; q4 < VEC / 4; ++q4) {
+        const f32x4 c4 = cs[q4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.set(q4 * 4 + j, v.get(q4 * 4 + j) * ps * c4[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o.set(j, v.get(j) * ps);
+    }
     stg16(out + e, o);
   }
 }
@@ -456,17 +470,25 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
-// dx = dout*scale[b][c] + dpool[b][c]/HW
+// dx = dout*scale[b][c] + dpool[b][c]/HW   (same thread / index scheme as scale_kernel)
 template <typename T>
-__global__ void se_bwd_apply_kernel(const T* __restrict__ dout, const float* __restrict__ scale, const float* __restrict__ dpool,
-                                    T* __restrict__ dx, size_t nvec, int HW, int C) {
+__global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__ dout, const float* __restrict__ scale, const float* __restrict__ dpool,
+                                                           T* __restrict__ dx, unsigned npix, int HW, int C, unsigned long long mul_hw) {
   constexpr int VEC = Vec16<T>::N;
   const float inv = 1.f / (float)HW;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t e = i * VEC; const int c0 = (int)(e % C); const size_t b = e / C / HW;
+  const int cv = C / VEC, lanes_r = 256 / cv, c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
+  for (unsigned pix = blockIdx.x * lanes_r + myr; pix < npix; pix += gridDim.x * lanes_r) {
+    const size_t e = (size_t)pix * C + c0;
+    const unsigned b = (unsigned)(((unsigned long long)pix * mul_hw) >> 40);
+    const f32x4* sp = reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c0);
+    const f32x4* dp = reinterpret_cast<const f32x4*>(dpool + (size_t)b * C + c0);
     Vec16<T> d = ldg16(dout + e), o;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o.set(j, d.get(j) * scale[b * C + c0 + j] + dpool[b * C + c0 + j] * inv);
+    for (int q4 = 0; q4 < VEC / 4; ++q4) {
+      const f32x4 s4 = sp[q4], p4 = dp[q4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.set(q4 * 4 + j, d.get(q4 * 4 + j) * s4[j] + p4[j] * inv);
+    }
     stg16(dx + e, o);
   }
 }
@@ -570,11 +592,12 @@ __global__ void spatial_bwd_conv_kernel(const float* __restrict__ dpre, const fl
 // dx = dout*amap[p] + dpool2[p][1]/C + (c == amax[p]) * dpool2[p][0]
 template <typename T>
 __global__ void spatial_bwd_apply_kernel(const T* __restrict__ dout, const float* __restrict__ amap, const float* __restrict__ dpool2,
-                                         const int* __restrict__ amax, T* __restrict__ dx, size_t nvec, int C) {
+                                         const int* __restrict__ amax, T* __restrict__ dx, unsigned npix, int C) {
   constexpr int VEC = Vec16<T>::N;
   const float inv = 1.f / (float)C;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t e = i * VEC; const int c0 = (int)(e % C); const size_t p = e / C;
+  const int cv = C / VEC, lanes_r = 256 / cv, c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
+  for (unsigned p = blockIdx.x * lanes_r + myr; p < npix; p += gridDim.x * lanes_r) {
+    const size_t e = (size_t)p * C + c0;
     Vec16<T> d = ldg16(dout + e), o;
     const float a = amap[p], dm = dpool2[p * 2], da = dpool2[p * 2 + 1] * inv; const int mi = amax[p];
 #pragma unroll
@@ -620,6 +643,9 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict_
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+// grid for the pixel-walking elementwise kernels (a thread owns a channel vector): enough workgroups to cover the pixels, capped
+static inline int px_grid(size_t npix, int C, int VEC) { const size_t lr = 256 / (C / VEC), g = (npix + lr - 1) / lr; return (int)(g > 16384 ? 16384 : (g ? g : 1)); }
+static inline unsigned long long magic40(unsigned d) { return ((1ull << 40) + d - 1) / d; }   // (x * m) >> 40 == x / d for x*d < 2^40
 static inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 16384 ? 16384 : (g ? g : 1)); }
 static inline int row_grid(size_t rows, int lanes_r) { size_t g = (rows + lanes_r - 1) / lanes_r; return (int)(g > 8192 ? 8192 : (g ? g : 1)); }
 #define DT(call_f, call_b) do { if (dtype) { call_b; } else { call_f; } } while (0)
@@ -721,9 +747,10 @@ int vqa_se_fwd(int dtype, const void* x, const float* w1, const float* w2, float
   const size_t shm = ((size_t)256 * VEC + C + Cr) * 4;
   DT(hipLaunchKernelGGL(se_pool_fc_kernel<float>, dim3(B), dim3(256), shm, st, (const float*)x, w1, w2, pooled, hidden, scale, HW, C, Cr),
      hipLaunchKernelGGL(se_pool_fc_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)x, w1, w2, pooled, hidden, scale, HW, C, Cr));
-  const size_t nvec = (size_t)B * HW * C / VEC;
-  DT(hipLaunchKernelGGL(scale_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, scale, (const float*)nullptr, (float*)out, nvec, HW, C),
-     hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x, scale, (const float*)nullptr, (bf16_t*)out, nvec, HW, C));
+  const size_t npix = (size_t)B * HW;
+  if (npix >= (1ull << 28)) return VQA_EARG;
+  DT(hipLaunchKernelGGL(scale_kernel<float>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const float*)x, scale, (const float*)nullptr, (float*)out, (unsigned)npix, C, magic40(HW)),
+     hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const bf16_t*)x, scale, (const float*)nullptr, (bf16_t*)out, (unsigned)npix, C, magic40(HW)));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // scratch: dz2[B*C] | dh[B*Cr] | dpool[B*C] floats
@@ -735,9 +762,10 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   const size_t shm = ((size_t)256 * VEC + C + Cr) * 4;
   DT(hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, dim3(B), dim3(256), shm, st, (const float*)dout, (const float*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr),
      hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr));
-  const size_t nvec = (size_t)B * HW * C / VEC;
-  DT(hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)dout, scale, dpool, (float*)dx, nvec, HW, C),
-     hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)dout, scale, dpool, (bf16_t*)dx, nvec, HW, C));
+  const size_t npix = (size_t)B * HW;
+  if (npix >= (1ull << 28)) return VQA_EARG;
+  DT(hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const float*)dout, scale, dpool, (float*)dx, (unsigned)npix, HW, C, magic40(HW)),
+     hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const bf16_t*)dout, scale, dpool, (bf16_t*)dx, (unsigned)npix, HW, C, magic40(HW)));
   hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 255) / 256, B >= 64 ? 8 : 1), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
@@ -750,9 +778,9 @@ int vqa_spatial_fwd(int dtype, const void* x, const float* w, float* pooled2, in
   DT(hipLaunchKernelGGL(spatial_pool_kernel<float>, dim3(pg), dim3(256), 0, st, (const float*)x, pooled2, amax, npix, C),
      hipLaunchKernelGGL(spatial_pool_kernel<bf16_t>, dim3(pg), dim3(256), 0, st, (const bf16_t*)x, pooled2, amax, npix, C));
   hipLaunchKernelGGL(spatial_conv_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, pooled2, w, amap, B, H, W);
-  const size_t nvec = npix * C / VEC;
-  DT(hipLaunchKernelGGL(scale_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, (const float*)nullptr, amap, (float*)out, nvec, H * W, C),
-     hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x, (const float*)nullptr, amap, (bf16_t*)out, nvec, H * W, C));
+  if (npix >= (1ull << 28) || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  DT(hipLaunchKernelGGL(scale_kernel<float>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const float*)x, (const float*)nullptr, amap, (float*)out, (unsigned)npix, C, magic40(H * W)),
+     hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const bf16_t*)x, (const float*)nullptr, amap, (bf16_t*)out, (unsigned)npix, C, magic40(H * W)));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // scratch: dpre[B*H*W] | dpool2[B*H*W*2] floats
@@ -766,9 +794,9 @@ int vqa_spatial_bwd(int dtype, const void* dout, const void* x, const float* w, 
   DT(hipLaunchKernelGGL(spatial_bwd_reduce_kernel<float>, dim3(pg), dim3(256), 0, st, (const float*)dout, (const float*)x, amap, dpre, npix, C),
      hipLaunchKernelGGL(spatial_bwd_reduce_kernel<bf16_t>, dim3(pg), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, amap, dpre, npix, C));
   hipLaunchKernelGGL(spatial_bwd_conv_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, dpre, w, dpool2, B, H, W);
-  const size_t nvec = npix * C / VEC;
-  DT(hipLaunchKernelGGL(spatial_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)dout, amap, dpool2, amax, (float*)dx, nvec, C),
-     hipLaunchKernelGGL(spatial_bwd_apply_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)dout, amap, dpool2, amax, (bf16_t*)dx, nvec, C));
+  if (npix >= (1ull << 28) || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  DT(hipLaunchKernelGGL(spatial_bwd_apply_kernel<float>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const float*)dout, amap, dpool2, amax, (float*)dx, (unsigned)npix, C),
+     hipLaunchKernelGGL(spatial_bwd_apply_kernel<bf16_t>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const bf16_t*)dout, amap, dpool2, amax, (bf16_t*)dx, (unsigned)npix, C));
   hipLaunchKernelGGL(spatial_wgrad_kernel, dim3(98, 16), dim3(256), 0, st, dpre, pooled2, dw, B, H, W);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
