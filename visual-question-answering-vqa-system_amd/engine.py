@@ -36,6 +36,8 @@ class HipEngine:
         self._wt_plan: Dict[str, tuple] = {}      # operands packed by begin_step (filled by _packT on first use)
         self._wt_table = None
         self._wt_buf = None
+        self.defer_tail = os.environ.get("VQA_DEFER_TAIL", "1") != "0"
+        self._deferred = []
         self.fold_eval = True                     # inference (eval, no tape): Conv+BN folded, BN never runs as its own pass
         self._fold = None                         # (key, table, nd, blocks, wbuf, bbuf, views)
         self.stem_w = None
@@ -266,11 +268,16 @@ class HipEngine:
         return K.layernorm_bwd(dout, x, self.P(prefix + ".weight"), stats, G[eg.offset: eg.offset + eg.numel],
                                G[eb.offset: eb.offset + eb.numel], addend=addend, drop_p=p, seed=seed, dadd=dadd, period=period)
 
-    def _off_path(self, tensors, fn):
+    def _off_path(self, tensors, fn, defer=False):
         """Run fn (a weight-gradient launch) on the second side stream: it only needs `tensors` (already produced on the
-        current stream) and writes its own slice of G, so it may overlap the data-gradient chain."""
+        current stream) and writes its own slice of G, so it may overlap the data-gradient chain.
+        defer: keep it back until _flush_deferred() -- the last residual block's weight gradients are released when the stem
+        backward starts, so that the (latency-bound) fused stem weight-gradient kernel does not run alone at the end of the step."""
         if not (self.wgrad_stream and self.two_streams and self.side2 is not None):
             return fn()
+        if defer and self.defer_tail:
+            self._deferred.append((tensors, fn))
+            return
         cur = torch.cuda.current_stream()
         ev = torch.cuda.Event(); ev.record(cur)
         self.side2.wait_event(ev)
@@ -279,7 +286,13 @@ class HipEngine:
         with torch.cuda.stream(self.side2):
             fn()
 
+    def _flush_deferred(self):
+        d, self._deferred = self._deferred, []
+        for tensors, fn in d:
+            self._off_path(tensors, fn)
+
     def _join_off_path(self):
+        self._flush_deferred()
         if self.wgrad_stream and self.two_streams and self.side2 is not None:
             ev = torch.cuda.Event(); ev.record(self.side2)
             torch.cuda.current_stream().wait_event(ev)
@@ -681,6 +694,7 @@ class HipEngine:
         bnp = "image_encoder.stem.1"
         call("vqa_bn_bwd_finalize", ptr(slab), nb, 64, 1, float(B * H1 * W1), ptr(self.P(bnp + ".weight")), ptr(st["coef"]),
              int(training), ptr(self._gslice(G, bnp + ".weight")), ptr(self._gslice(G, bnp + ".bias")), ptr(bc))
+        self._flush_deferred()                    # stage-1 block-0 weight gradients run beside the stem weight gradient
         if self.stem_w2 is not None and K.stem_conv_blocks(B, IH, IW) > 0:
             # dy (B x 112 x 112 x 64) is never written: the weight-gradient kernel rebuilds it row by row
             dwv = self._gslice(G, "image_encoder.stem.0.weight")
@@ -705,6 +719,7 @@ class HipEngine:
         T = self.dtype
         p, Cout, Cin, M = rec["p"], rec["Cout"], rec["Cin"], rec["M"]
         has_ds = "yd" in rec
+        last = p == "image_encoder.stage1.blocks.0"           # its weight gradients are released with the stem backward (deferring all of stage 1 measured worse)
         gs = lambda n: self._gslice(G, n)
         dy2, dyd = K.bn_bwd(dout, rec["out"], rec["y2"], rec["c2"], self.P(p + ".bn2.weight"), Cout, training,
                             gs(p + ".bn2.weight"), gs(p + ".bn2.bias"),
@@ -715,7 +730,7 @@ class HipEngine:
         g2 = rec["g2"]; B, Ho, Wo = g2[0], g2[1], g2[2]
         c64_2 = self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1)
         if self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1, wgrad=True):
-            self._off_path([dy2], lambda: K.wgrad3x3_c64(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo))
+            self._off_path([dy2], lambda: K.wgrad3x3_c64(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo), defer=last)
         else:
             self._off_path([dy2], lambda: K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T))
         if c64_2:
@@ -728,7 +743,7 @@ class HipEngine:
         g1 = rec["g1"]; H, W, stride = g1[1], g1[2], g1[8]
         c64_1 = self._c64_ok(B, H, W, Cin, Cout, 3, stride)
         if self._c64_ok(B, H, W, Cin, Cout, 3, stride, wgrad=True):
-            self._off_path([dy1], lambda: K.wgrad3x3_c64(rec["x"], dy1, LY.mat_of(G, self.E[p + ".conv1.weight"]), B, H, W))
+            self._off_path([dy1], lambda: K.wgrad3x3_c64(rec["x"], dy1, LY.mat_of(G, self.E[p + ".conv1.weight"]), B, H, W), defer=last)
         else:
             self._off_path([dy1], lambda: K.wgrad(dy1, rec["x"], LY.mat_of(G, self.E[p + ".conv1.weight"]), M, Cout, 9 * Cin, g1, dtype=T))
         Md = B * H * W
