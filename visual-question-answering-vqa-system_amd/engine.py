@@ -38,6 +38,7 @@ class HipEngine:
         self._wt_buf = None
         self.defer_tail = os.environ.get("VQA_DEFER_TAIL", "1") != "0"
         self._deferred = []
+        self._stem_fcoef = None
         self.fold_eval = True                     # inference (eval, no tape): Conv+BN folded, BN never runs as its own pass
         self._fold = None                         # (key, table, nd, blocks, wbuf, bbuf, views)
         self.stem_w = None
@@ -126,9 +127,17 @@ class HipEngine:
         call("vqa_fold_bn_batch", K.dt(self.dtype), ptr(self.flat), ptr(wbuf), ptr(bbuf), ptr(table), nd, blk, 1e-5)
         return {w: (wbuf[wo: wo + n * k].view(n, k), bbuf[bo: bo + n]) for w, (wo, bo, n, k) in views.items()}
 
+    def _make_stem_fcoef(self):
+        gam, bet = self.P("image_encoder.stem.1.weight"), self.P("image_encoder.stem.1.bias")
+        fcoef = torch.zeros((4, 64), device=self.flat.device, dtype=torch.float32)
+        fcoef[2] = bet
+        fcoef[3] = torch.where(gam.abs() > 1e-20, 1.0 / gam, torch.zeros_like(gam))
+        return fcoef
+
     def begin_step(self):
         """Refresh the working copies of the weights (one cast of the whole flat buffer in bf16 mode)."""
         self._wt = {}
+        self._stem_fcoef = self._make_stem_fcoef() if self._wt_plan else None    # only once a backward has been seen (training)
         self._pack_planned()
         if self.dtype == torch.bfloat16:
             if self.wsrc is self.flat or self.wsrc.numel() != self.flat.numel():
@@ -683,9 +692,9 @@ class HipEngine:
         # which is the generic BN-backward reduction with y := pooled, mean := beta, invstd := 1/gamma.
         pooled = tape["stages"][0]["blocks"][0]["x"]
         gam, bet = self.P("image_encoder.stem.1.weight"), self.P("image_encoder.stem.1.bias")
-        fcoef = torch.zeros((4, 64), device=dxc.device, dtype=torch.float32)
-        fcoef[2] = bet
-        fcoef[3] = torch.where(gam.abs() > 1e-20, 1.0 / gam, torch.zeros_like(gam))
+        fcoef = self._stem_fcoef                  # (0, 0, beta, 1/gamma), built in begin_step: off the tail of the step
+        if fcoef is None:
+            fcoef = self._make_stem_fcoef()
         rows_p = pooled.numel() // 64
         nb = K.L.count("vqa_bn_bwd_blocks", rows_p)
         slab = torch.empty((nb, 3, 64), device=dxc.device, dtype=torch.float32)
