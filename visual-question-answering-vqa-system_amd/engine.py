@@ -595,6 +595,7 @@ class HipEngine:
         training = tape["training"]
         B = tape["B"]
         seg = on_segment or (lambda name: None)
+        self._deferred = []                       # (a backward that raised must not leak its held-back launches into this one)
         dl = dlogits.to(T).contiguous() if dlogits.dtype != T else dlogits.contiguous()
 
         # ---- head
