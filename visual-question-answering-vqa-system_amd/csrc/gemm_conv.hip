@@ -611,7 +611,13 @@ struct WgradParams {
 // 8 different 32-byte bank slots (the padded layout was 2-way conflicted).  fp32 keeps the padded layout (plain ds_read_b32).
 template <typename T, int WIDTH> __device__ __forceinline__ int kmaj_off(int k, int col) {
   if constexpr (sizeof(T) == 2) {
-    const int h = (WIDTH == 128) ? ((k & 3) | (((k >> 3) & 1) << 2)) : (((k >> 1) & 1) | (((k >> 3) & 1) << 1));
+    // reads (ds_read_b64_tr_b16, 32-lane groups touch rows {0..3, 8..11} + 16n): h must be injective on k bits {0, 1, 3} (WIDTH 128:
+    // a row is the whole 256-byte bank window) resp. on bits {1, 3} for a fixed bit 0 (WIDTH 64: bit 0 picks the window half).
+    // staging stores (ds_write_b128, 8-lane groups = 64 bytes of row r and of row r + 1, 128-byte bank window): the two rows must
+    // land in different 64-byte halves, i.e. k bit 0 has to drive chunk-index bit 1 (it drove bit 0 / nothing: 2-way conflicts,
+    // SQ_LDS_BANK_CONFLICT = 20 % of the LDS cycles).
+    const int h = (WIDTH == 128) ? (((k & 1) << 1) | ((k >> 1) & 1) | (((k >> 3) & 1) << 2))
+                                 : ((((k >> 1) & 1) | (((k >> 3) & 1) << 1)) ^ ((k & 1) << 1));
     return k * WIDTH + ((((col >> 4) ^ h) << 4) | (col & 15));
   } else {
     return k * (WIDTH + 4) + col;
