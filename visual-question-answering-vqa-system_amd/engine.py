@@ -134,11 +134,13 @@ class HipEngine:
         fcoef[3] = torch.where(gam.abs() > 1e-20, 1.0 / gam, torch.zeros_like(gam))
         return fcoef
 
-    def begin_step(self):
+    def begin_step(self, for_backward: bool = True):
         """Refresh the working copies of the weights (one cast of the whole flat buffer in bf16 mode)."""
         self._wt = {}
-        self._stem_fcoef = self._make_stem_fcoef() if self._wt_plan else None    # only once a backward has been seen (training)
-        self._pack_planned()
+        self._stem_fcoef = None
+        if for_backward:                          # inference (no tape) needs neither the transposed weights nor the stem helper
+            self._stem_fcoef = self._make_stem_fcoef() if self._wt_plan else None    # only once a backward has been seen
+            self._pack_planned()
         if self.dtype == torch.bfloat16:
             if self.wsrc is self.flat or self.wsrc.numel() != self.flat.numel():
                 self.wsrc = torch.empty(self.flat.numel(), device=self.flat.device, dtype=torch.bfloat16)
@@ -315,7 +317,7 @@ class HipEngine:
                 want_aux: bool = False, need_tape: bool = True):
         cfg, T = self.cfg, self.dtype
         self._site = 0
-        self.begin_step()
+        self.begin_step(for_backward=need_tape)
         tape: dict = {"training": training, "B": images.shape[0]}
         B, _, IH, IW = images.shape
         pdrop = cfg["dropout"] if training else 0.0
