@@ -27,6 +27,10 @@ typedef struct ihipStream_t* hipStream_t;
  * stats != NULL: per-M-tile column sums / sums of squares ([vqa_igemm_mtiles][2][N]) for train-mode BatchNorm.
  * transposed = 1 gathers for the data gradient (a = dY [B,H,W,C], rows index dX [B,Ho,Wo]). */
 int vqa_igemm_mtiles(int M, int N, int loader);
+/* which template instantiation vqa_igemm launches for this problem (host-only query, no launch):
+ * BM*10000 + BN*10 + flavour (0 plain LDS-DMA double buffer, 1 window loader, 2/3 8-wave 256x128 ring, 4/5 BK=32 shapes) */
+int vqa_igemm_variant(int dtype, int loader, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
+                      int R, int S, int stride, int pad);
 int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, const float* bias, const void* addend,
               const void* addmask, float* stats, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
@@ -145,9 +149,11 @@ int vqa_add(int dtype, const void* a, const void* b, void* out, long long n, hip
 /* gradient at the pre-activation of linear(+bias)(+ReLU)(+dropout); dbias += column sums */
 int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, float* dbias, int M, int N, float p,
                      unsigned long long seed, hipStream_t stream);
-/* nn.CrossEntropyLoss() mean (training/train.py:120): loss += mean NLL, dlogits = (softmax-onehot)*gscale/B */
+/* nn.CrossEntropyLoss() mean (training/train.py:120): loss += mean NLL, dlogits = (softmax-onehot)*gscale/B.
+   err (device int, may be NULL): += number of rows whose target is outside [0, N) -- the reference raises there; such rows are
+   never read out of bounds, they add NaN to the loss and get a NaN gradient row. */
 int vqa_cross_entropy(int dtype, const void* logits, const long long* targets, float* loss, void* dlogits, float* logits_f32,
-                      int B, int N, float gscale, hipStream_t stream);
+                      int B, int N, float gscale, int* err, hipStream_t stream);
 int vqa_convert(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
 /* clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (training/train.py:204-208,127-132) */
 int vqa_sumsq(const float* g, long long n, float* out /* >= 2049 floats: [0] result (bit-reproducible), rest scratch */, hipStream_t stream);

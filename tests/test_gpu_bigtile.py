@@ -1,0 +1,140 @@
+"""GPU parity of the kernel instantiations the BENCHMARK times (bf16, B=512/GPU), at shapes large enough that the C dispatch
+picks them -- the small-shape cases of test_gpu_gemm_conv.py all fall to the 64x64 tile (fewer than 384 tiles).
+
+Every case asserts through `vqa_igemm_variant` (the same host function the launch uses) which template runs, then compares
+with ATen's CPU convolution / autograd on bf16-rounded operands (fp32 math), so only accumulation order and the final bf16
+rounding differ: forward and data gradient 1.2e-2 of the output scale, weight gradient (fp32 output) 3e-3.
+
+  stage 1  B=16   64->64   56x56   M=50176  392 tiles of 128x64   window loader <128,64,...,1>   (reference conv: cnn_backbone.py:182-187)
+  stage 2  B=64  128->128  28x28   M=50176  392 tiles of 128x128  window loader <128,128,...,1>
+  stage 3  B=128 256->256  14x14   M=25088  392 tiles
+  stage 4  B=256 512->512   7x7    M=12544  392 tiles
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _pkg import sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _round(t):
+    return t.to(BF).float()
+
+
+def _relerr(got, ref):
+    return float((got - ref).abs().max() / ref.abs().max().clamp(min=1e-6))
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+STAGES = [  # B, C, H, expected variant (BM*10000 + BN*10 + 1 = window loader)
+    (16, 64, 56, 128 * 10000 + 64 * 10 + 1),
+    (64, 128, 28, 128 * 10000 + 128 * 10 + 1),
+    (128, 256, 14, 128 * 10000 + 128 * 10 + 1),
+    (256, 512, 7, 128 * 10000 + 128 * 10 + 1),
+]
+
+
+@pytest.mark.parametrize("case", STAGES)
+def test_window_loader_conv_fwd_and_dgrad_at_benchmark_tiles(case):
+    """conv3x3/1 forward (+ BN partial statistics) and its data gradient (+ masked identity addend, the block's residual path)."""
+    K = sub("kernels")
+    B, C, H, want = case
+    g = torch.Generator().manual_seed(C + H)
+    x = _round(torch.randn(B, C, H, H, generator=g))
+    w = _round(torch.randn(C, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5)
+    dy = _round(torch.randn(B, C, H, H, generator=g))
+    add = _round(torch.randn(B, C, H, H, generator=g))
+    msk = _round(torch.randn(B, C, H, H, generator=g))
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, None, stride=1, padding=1)
+    yr.backward(dy)
+    M, Kw = B * H * H, 9 * C
+    geom = (B, H, H, C, H, H, 3, 3, 1, 1)
+    assert K.igemm_variant(BF, K.LOADER_NHWC, M, C, Kw, geom) == want
+    w_krsc = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    K.PROFILE = []
+    try:
+        y, stats, mt = K.igemm(_nhwc(x).to(DEV, BF), K.pack_rows(w_krsc.view(C, Kw), BF), M, C, Kw, geom, dtype=BF, want_stats=True)
+        wt = K.pack_transpose(w_krsc.view(C, 9, C), BF)
+        dx, _, _ = K.igemm(_nhwc(dy).to(DEV, BF), wt, M, C, Kw, geom, dtype=BF, transposed=1,
+                           addend=_nhwc(add).to(DEV, BF), addmask=_nhwc(msk).to(DEV, BF))
+        torch.cuda.synchronize()
+        names = [r[0] for r in K.PROFILE]
+    finally:
+        K.PROFILE = None
+    assert all(n.endswith(", 4, 64, 2, 2, 1>") for n in names), names           # window-loader instantiation, both launches
+    y_ref = _nhwc(yr.detach()).reshape(M, C)
+    assert _relerr(y.float().cpu(), y_ref) < 1.2e-2
+    s = stats.sum(dim=0).cpu()
+    assert mt == (M + 127) // 128
+    assert _relerr(s[0], y_ref.sum(0)) < 5e-3 and _relerr(s[1], (y_ref ** 2).sum(0)) < 5e-3
+    dx_ref = _nhwc(xr.grad + add * (msk > 0)).reshape(M, C)
+    assert _relerr(dx.float().cpu(), dx_ref) < 1.2e-2
+
+
+def test_plain_128_tiles_linear_at_benchmark_rows():
+    """The token-side Linears of a B=512 step run the plain (non-window) 128x128 / 128x64 bf16 tiles: M = 512*49 rows."""
+    K = sub("kernels")
+    g = torch.Generator().manual_seed(3)
+    for M, Kin, N, want in ((25088, 512, 256, 128 * 10000 + 128 * 10), (50176, 256, 64, 128 * 10000 + 64 * 10)):
+        x = _round(torch.randn(M, Kin, generator=g))
+        w = _round(torch.randn(N, Kin, generator=g) / Kin ** 0.5)
+        b = torch.randn(N, generator=g)
+        geom = K.linear_geom(M, Kin)
+        assert K.igemm_variant(BF, K.LOADER_NHWC, M, N, Kin, geom) == want
+        out, _, _ = K.igemm(x.to(DEV, BF), K.pack_rows(w.to(DEV), BF), M, N, Kin, geom, dtype=BF, bias=b.to(DEV), relu=1)
+        torch.cuda.synchronize()
+        assert _relerr(out.float().cpu(), torch.relu(x @ w.t() + b)) < 1.2e-2
+
+
+WGRAD = [  # B, Cin, Cout, H, R, stride, pad, note
+    (128, 128, 128, 28, 3, 1, 1, "stage 2: 128x128 tile, inputs >= 80x dW -> XCD-aware workgroup order"),
+    (64, 64, 128, 56, 3, 2, 1, "stage-2 entry conv 3x3/2: 128x64 tile, XCD-aware order"),
+    (64, 64, 128, 56, 1, 2, 0, "stage-2 shortcut 1x1/2: 128x64 tile"),
+    (128, 256, 256, 14, 3, 1, 1, "stage 3: 128x128 tile, plain order"),
+    (256, 512, 512, 7, 3, 1, 1, "stage 4: 128x128 tile, plain order, 144 output tiles"),
+    (128, 128, 256, 28, 3, 2, 1, "stage-3 entry conv 3x3/2"),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD)
+def test_wgrad_at_benchmark_tiles(case):
+    K = sub("kernels")
+    B, Cin, Cout, H, R, stride, pad, _ = case
+    g = torch.Generator().manual_seed(Cin * 3 + H + R)
+    Ho = (H + 2 * pad - R) // stride + 1
+    x = _round(torch.randn(B, Cin, H, H, generator=g))
+    dy = _round(torch.randn(B, Cout, Ho, Ho, generator=g))
+    w = torch.zeros(Cout, Cin, R, R, requires_grad=True)
+    F.conv2d(x, w, None, stride=stride, padding=pad).backward(dy)
+    M, Kw = B * Ho * Ho, R * R * Cin
+    geom = (B, H, H, Cin, Ho, Ho, R, R, stride, pad)
+    dw = torch.zeros(Cout, Kw, device=DEV)
+    K.wgrad(_nhwc(dy).to(DEV, BF), _nhwc(x).to(DEV, BF), dw, M, Cout, Kw, geom, dtype=BF)
+    torch.cuda.synchronize()
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, Kw)
+    assert _relerr(dw.cpu(), ref) < 3e-3
+    # += semantics: a second launch into the same buffer doubles it
+    K.wgrad(_nhwc(dy).to(DEV, BF), _nhwc(x).to(DEV, BF), dw, M, Cout, Kw, geom, dtype=BF)
+    torch.cuda.synchronize()
+    assert _relerr(dw.cpu(), 2 * ref) < 3e-3
+
+
+def test_token_side_wgrad_at_benchmark_rows():
+    """Weight gradients of the token-side Linears at B=512: M = 10240 (text) / 25088 (image tokens) rows, small N x K."""
+    K = sub("kernels")
+    g = torch.Generator().manual_seed(11)
+    for M, Kin, N in ((10240, 256, 768), (10240, 1024, 256), (10240, 256, 1024), (25088, 512, 256), (25088, 256, 512), (512, 256, 1000)):
+        x = _round(torch.randn(M, Kin, generator=g))
+        dy = _round(torch.randn(M, N, generator=g))
+        dw = torch.zeros(N, Kin, device=DEV)
+        K.wgrad(dy.to(DEV, BF), x.to(DEV, BF), dw, M, N, Kin, K.linear_geom(M, Kin), dtype=BF)
+        torch.cuda.synchronize()
+        assert _relerr(dw.cpu(), dy.t() @ x) < 3e-3, (M, Kin, N)

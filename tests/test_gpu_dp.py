@@ -41,9 +41,24 @@ def _worker(rank, world, port, q):
     model = fresh()
     tr = P.trainer.HipTrainer(model, lr=1e-3)
     assert tr.world == 2
+    before = model._flat.detach().clone()
+    # the data-parallel backward must not join the weight-gradient stream into the data-gradient stream per stage (only the
+    # reducer's communication stream waits for both): exactly ONE join, at the end of backward
+    eng0 = tr.engine
+    joins, orig_join = [], eng0._join_off_path
+    eng0._join_off_path = lambda: (joins.append(1), orig_join())[1]
     tr.step(*shard)
     torch.cuda.synchronize()
     g_sum = tr.G.clone()
+    n_joins = len(joins)
+    issued_all = len(tr.buckets)
+    # clip + AdamW on the REDUCED gradient: g = G_sum / world, global norm over g, first AdamW step (m = v = 0)
+    gm = g_sum.double() / world
+    norm = gm.norm()
+    gc = gm * min(1.0, 1.0 / (float(norm) + 1e-6))
+    expect = before.double() * (1 - 1e-3 * 0.01) - 1e-3 * gc / (gc.abs() + 1e-8)
+    upd_err = (model._flat.detach().double() - expect).abs().max().item()
+    norm_err = abs(float(tr.grad_norm()) - float(norm)) / float(norm)
     # reference: this rank's own gradient without any reduction, summed over ranks by a plain all_reduce
     m2 = fresh()
     eng = m2._ensure_engine()
@@ -51,7 +66,7 @@ def _worker(rank, world, port, q):
     logits, _, tape = eng.forward(shard[0], shard[1], shard[2].float(), True, False, need_tape=True)
     dl = torch.empty_like(logits)
     loss = torch.zeros(1, device="cuda")
-    P._lib.call("vqa_cross_entropy", 0, logits.data_ptr(), shard[3].data_ptr(), loss.data_ptr(), dl.data_ptr(), None, 2, 40, 1.0)
+    P._lib.call("vqa_cross_entropy", 0, logits.data_ptr(), shard[3].data_ptr(), loss.data_ptr(), dl.data_ptr(), None, 2, 40, 1.0, None)
     eng.backward(tape, dl, G2)
     torch.cuda.synchronize()
     ref = G2.cpu()
@@ -63,7 +78,7 @@ def _worker(rank, world, port, q):
     dist.broadcast(other, src=0)
     same = torch.equal(mine, other)
     moved = not torch.equal(mine, m2._flat.detach().cpu())
-    q.put((rank, err, same, moved))
+    q.put((rank, err, same, moved, n_joins, upd_err, norm_err))
     dist.destroy_process_group()
 
 
@@ -78,6 +93,8 @@ def test_two_rank_train_step_over_gloo_on_one_gpu():
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, err, same, moved in res:
-        assert err < 1e-5, (rank, err)        # fp32 sums of the same two gradients (atomics reorder the last bits)
+    for rank, err, same, moved, n_joins, upd_err, norm_err in res:
+        assert err < 1e-5, (rank, err)        # fp32 sums of the same two gradients
         assert same and moved
+        assert n_joins == 1, n_joins          # un-serialised: no per-stage join of the weight-gradient stream
+        assert upd_err < 2e-6 and norm_err < 1e-5, (upd_err, norm_err)      # 1/world, clip and AdamW act on the reduced gradient

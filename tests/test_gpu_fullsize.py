@@ -38,6 +38,29 @@ def test_config1_fp32_batch256_eval_matches_oracle_and_is_batch_independent():
     assert (big[:4].argmax(-1).cpu() == ref.argmax(-1)).all()
 
 
+def test_config2_bf16_batch512_eval_matches_oracle_on_first_samples():
+    """BASELINE configs[2] shapes (B=512 bf16: every conv / Linear runs the 128-row tiles, the window loader, the XCD-aware tile
+    order): eval-mode BatchNorm makes a sample's logits independent of the rest of the batch, so the first samples of the big
+    batch must match the pinned CPU oracle run on just those samples.  bf16 bound as in test_gpu_model: 5e-2 on logits."""
+    cfg = O.full_config()
+    sd = O.init_state_dict(cfg, 23, jitter=True)
+    m = _model("bf16", sd, cfg).eval()
+    m._ensure_engine().fold_eval = False                 # BN as its own pass: the train-step forward kernels, eval statistics
+    images, ids, mask, _ = O.synthetic_batch(512, seed=2025)
+    with torch.no_grad():
+        big, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
+        m._engine.fold_eval = True                       # and the folded inference path at the same size
+        folded, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
+        ref, _ = O.vqa_forward(images[:8], ids[:8], mask[:8], sd, cfg, training=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(big).all() and torch.isfinite(folded).all()
+    assert (big[:8].cpu() - ref).abs().max().item() < 5e-2
+    assert (folded[:8].cpu() - ref).abs().max().item() < 5e-2
+    # and the last samples too (tile tails / the far end of the XCD tile ranges)
+    ref2, _ = O.vqa_forward(images[-4:], ids[-4:], mask[-4:], sd, cfg, training=False)
+    assert (big[-4:].cpu() - ref2).abs().max().item() < 5e-2
+
+
 @pytest.mark.parametrize("dtype,B", [("fp32", 256), ("bf16", 512)])
 def test_full_size_train_step_invariants(dtype, B):
     P = pkg()

@@ -119,8 +119,11 @@ def test_train_step_fp32_matches_reference_golden(golden_dir, tag, cfgkw, seed, 
 
 
 def test_train_bf16_grads_close_to_oracle():
-    """bf16 path, B=8, dropout 0: compare loss and per-tensor gradient norms with the fp32 CPU oracle.
-    bf16 activations (8-bit mantissa) through 20 train-mode BN layers: loss within 2e-2, >=90% of tensors' grad norms within 15%."""
+    """bf16 path, B=8, dropout 0: loss and EVERY parameter tensor's gradient against the fp32 CPU oracle.
+    bf16 activations (8-bit mantissa) through 20 train-mode BN layers at batch 8; bounds (stated, measured worst case in the
+    assertion message): loss within 2e-2; per tensor the gradient DIRECTION must agree -- cosine >= 0.98 for the 2-D+ weights
+    that carry 99.9 % of the gradient mass (cosine catches a mis-permuted tile or a wrong halo mask that a norm check cannot) --
+    and every tensor's norm within 12 % (BatchNorm/LayerNorm affine vectors and biases: 25 %, a handful of elements each)."""
     cfg = O.full_config(dropout=0.0, answer_dropout=0.0)
     sd = O.init_state_dict(cfg, 7, jitter=True)
     m = _model(cfg, sd, "bf16").train()
@@ -135,11 +138,26 @@ def test_train_bf16_grads_close_to_oracle():
     assert abs(loss.item() - lref.item()) < 2e-2
     names = O.parameter_names(cfg)
     P = dict(m.named_parameters())
-    rel = np.array([abs(float(P[n].grad.norm()) - float(tr.sd[n].grad.norm())) / max(float(tr.sd[n].grad.norm()), 1e-8) for n in names])
-    assert (rel < 0.15).mean() >= 0.9, np.sort(rel)[-10:]
+    report = []
+    for n in names:
+        g, r = P[n].grad.detach().float().cpu().reshape(-1), tr.sd[n].grad.reshape(-1)
+        rn = float(r.norm())
+        if rn < 1e-10:                                  # (e.g. nothing reaches a tensor): then ours must vanish too
+            assert float(g.norm()) < 1e-6, n
+            continue
+        rel = abs(float(g.norm()) - rn) / rn
+        cos = float(torch.dot(g, r) / (g.norm() * r.norm()).clamp(min=1e-30))
+        report.append((n, rel, cos, P[n].dim()))
+    worst_rel = max(report, key=lambda t: t[1])
+    worst_cos = min(report, key=lambda t: t[2])
+    for n, rel, cos, dim in report:
+        assert rel < (0.12 if dim >= 2 else 0.25), (n, rel, "worst", worst_rel)
+        assert cos > (0.98 if dim >= 2 else 0.90), (n, cos, "worst", worst_cos)
 
 
 def test_train_dropout_runs_and_is_deterministic_per_seed():
+    """Model-level smoke of the dropout path (the per-site contract lives in tests/test_gpu_dropout.py): two training forwards
+    of the same batch differ (fresh masks per forward), gradients are finite, replaying the step counter replays the masks."""
     cfg = O.full_config()
     sd = O.init_state_dict(cfg, 5)
     m = _model(cfg, sd, "bf16").train()
@@ -147,10 +165,11 @@ def test_train_dropout_runs_and_is_deterministic_per_seed():
     a, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
     b, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
     torch.cuda.synchronize()
-    assert torch.isfinite(a).all() and torch.equal(a, b) is False or True
-    m._engine.step_id += 1
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert not torch.equal(a, b)
+    m._engine.step_id -= 2                               # replay the first forward's seeds
     c, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
-    assert not torch.equal(a, c)
+    assert torch.equal(a, c)
     torch.nn.functional.cross_entropy(c, answers.to(DEV)).backward()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
 

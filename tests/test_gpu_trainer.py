@@ -1,0 +1,178 @@
+"""GPU parity of the train-step tail the benchmark times (HipTrainer.step = zero_grad -> forward -> vqa_cross_entropy ->
+backward -> vqa_sumsq (+clip) -> vqa_adamw; reference recipe training/train.py:120,176-208, non-AMP branch) against
+(a) the goldens written by the REAL reference (tests/golden/{full,small}_train.npz: loss, clip norm, per-tensor post-AdamW
+deltas, BN running statistics), (b) three consecutive steps of the CPU oracle's OracleTrainer, and (c) torch's own
+F.cross_entropy / AdamW formulas for the individual kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _pkg import pkg, sub
+from oracle import vqa_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(cfg, sd, dtype="fp32"):
+    m = pkg().load_dropin().VQAModel(**cfg, compute_dtype=dtype)
+    m.load_state_dict(sd)
+    return m.to(DEV).train()
+
+
+@pytest.mark.parametrize("tag,cfgkw,seed,B,isz,L,vocab", [
+    ("full_train", dict(dropout=0.0, answer_dropout=0.0), 2, 4, 224, 20, 1000),
+    ("small_train", dict(dropout=0.0, answer_dropout=0.0, vocab_size=100, num_answers=10, embed_dim=32), 3, 2, 64, 10, 100),
+])
+def test_hiptrainer_step_matches_reference_golden(golden_dir, tag, cfgkw, seed, B, isz, L, vocab):
+    """Same seeds and tolerances as test_gpu_model.py::test_train_step_fp32_matches_reference_golden, but the whole step runs
+    through HipTrainer (fused CE, device-side clip norm, flat AdamW) instead of torch.optim / clip_grad_norm_."""
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    cfg = O.full_config(**cfgkw)
+    sd = O.init_state_dict(cfg, seed, jitter=True)
+    m = _model(cfg, sd)
+    tr = pkg().trainer.HipTrainer(m)                               # TrainingConfig defaults: lr 1e-4, wd 0.01, betas (0.9, 0.999), clip 1.0
+    images, ids, mask, answers = O.synthetic_batch(B, seed=seed + 100, image_size=isz, seq_len=L, vocab=vocab,
+                                                   num_answers=cfg["num_answers"])
+    names = O.parameter_names(cfg)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    loss, logits = tr.step(images.to(DEV), ids.to(DEV), mask.to(DEV), answers.to(DEV))
+    torch.cuda.synchronize()
+    tr.check()
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-3
+    assert abs(float(loss.item()) - float(g["loss"])) < 1e-4
+    gn = float(tr.grad_norm().item())
+    assert abs(gn - float(g["gnorm"])) / float(g["gnorm"]) < 5e-3
+    # per-tensor gradient norms straight from the flat gradient buffer
+    P = dict(m.named_parameters())
+    E = m._engine.E
+    norms = np.array([float(tr.G[E[n].offset: E[n].offset + E[n].numel].double().norm()) for n in names])
+    rel = np.abs(norms - g["grad_norms"]) / np.maximum(g["grad_norms"], 1e-6)
+    assert rel.max() < 2e-2, (names[int(rel.argmax())], rel.max())
+    delta = np.array([float((P[n].detach() - before[n]).double().norm()) for n in names])
+    np.testing.assert_allclose(delta, g["step_delta_norms"], rtol=2e-2, atol=1e-7)
+    st = m.state_dict()
+    bn_keys = [k for k in st if "running_" in k]
+    got = np.concatenate([st[k].cpu().numpy() for k in bn_keys])
+    assert np.abs(got - g["bn_running"]).max() < 1e-4
+    assert int(st["image_encoder.stem.1.num_batches_tracked"]) == 1
+
+
+def test_three_steps_track_the_oracle_trainer():
+    """Three consecutive steps (bias-correction exponents t = 1, 2, 3; moments carried over; BN buffers updated in between)
+    at the reproduce_issue.py scale, lr 1e-3 so the parameters move well above fp32 noise.  fp32, dropout 0."""
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0, vocab_size=100, num_answers=10, embed_dim=32)
+    sd = O.init_state_dict(cfg, 13, jitter=True)
+    m = _model(cfg, sd)
+    tr = pkg().trainer.HipTrainer(m, lr=1e-3)
+    ot = O.OracleTrainer(sd, cfg, lr=1e-3)
+    names = O.parameter_names(cfg)
+    start = {n: sd[n].clone() for n in names}
+    for step in range(3):
+        images, ids, mask, answers = O.synthetic_batch(4, seed=500 + step, image_size=64, seq_len=10, vocab=100, num_answers=10)
+        lo, _, gno = ot.step(images, ids, mask, answers)
+        loss, _ = tr.step(images.to(DEV), ids.to(DEV), mask.to(DEV), answers.to(DEV))
+        torch.cuda.synchronize()
+        assert abs(float(loss.item()) - float(lo)) < 2e-4 * (step + 1), step
+        assert abs(float(tr.grad_norm().item()) - float(gno)) / float(gno) < 1e-2, step
+    P = dict(m.named_parameters())
+    worst = 0.0
+    for n in names:
+        moved = (ot.sd[n].detach() - start[n]).norm().item()
+        err = (P[n].detach().cpu() - ot.sd[n].detach()).norm().item()
+        # AdamW moves every element by ~lr per step whatever the gradient's size: an element whose gradient is at the fp32
+        # noise floor may take a different direction, so compare per tensor against the distance travelled
+        worst = max(worst, err / max(moved, 1e-12))
+        assert err <= 0.15 * moved + 1e-7, (n, err, moved)
+    st = m.state_dict()
+    for k, v in ot.sd.items():
+        if "running_" in k:
+            assert (st[k].cpu() - v).abs().max().item() < 1e-4, k
+    assert int(st["image_encoder.stem.1.num_batches_tracked"]) == 3
+    assert tr.t == 3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cross_entropy_kernel_matches_torch(dtype):
+    L = sub("_lib")
+    g = torch.Generator().manual_seed(3)
+    for B, N in ((512, 1000), (7, 10), (33, 2000)):
+        logits = (torch.randn(B, N, generator=g) * 3).to(dtype)
+        tgt = torch.randint(0, N, (B,), generator=g)
+        ref_in = logits.float().requires_grad_(True)
+        ref = F.cross_entropy(ref_in, tgt)
+        ref.backward()
+        ld, td = logits.to(DEV), tgt.to(DEV)
+        loss = torch.zeros(1, device=DEV)
+        dl = torch.empty(B, N, device=DEV, dtype=dtype)
+        lf = torch.empty(B, N, device=DEV)
+        err = torch.zeros(1, device=DEV, dtype=torch.int32)
+        L.call("vqa_cross_entropy", L.dt(dtype), ld.data_ptr(), td.data_ptr(), loss.data_ptr(), dl.data_ptr(), lf.data_ptr(), B, N, 1.0,
+               err.data_ptr())
+        torch.cuda.synchronize()
+        assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+        tol = 1e-6 if dtype == torch.float32 else 4e-3 * float(ref_in.grad.abs().max())
+        assert (dl.float().cpu() - ref_in.grad).abs().max().item() < tol
+        assert torch.equal(lf.cpu(), logits.float())
+        assert int(err.item()) == 0
+
+
+def test_cross_entropy_rejects_out_of_range_targets():
+    """nn.CrossEntropyLoss raises on a target outside [0, C) (training/train.py:120); the kernel must never read out of
+    bounds: it counts the rows, poisons their loss / gradient with NaN, and HipTrainer.check() raises."""
+    L = sub("_lib")
+    B, N = 6, 10
+    logits = torch.randn(B, N, device=DEV)
+    tgt = torch.tensor([1, 10, 3, -1, 9, 1 << 40], device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    dl = torch.empty(B, N, device=DEV)
+    err = torch.zeros(1, device=DEV, dtype=torch.int32)
+    L.call("vqa_cross_entropy", 0, logits.data_ptr(), tgt.data_ptr(), loss.data_ptr(), dl.data_ptr(), None, B, N, 1.0, err.data_ptr())
+    torch.cuda.synchronize()
+    assert int(err.item()) == 3
+    assert torch.isnan(loss).all()
+    bad = torch.tensor([False, True, False, True, False, True])
+    assert torch.isnan(dl.cpu()[bad]).all() and torch.isfinite(dl.cpu()[~bad]).all()
+    # the trainer surfaces it
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0, vocab_size=100, num_answers=10, embed_dim=32)
+    m = _model(cfg, O.init_state_dict(cfg, 1))
+    tr = pkg().trainer.HipTrainer(m)
+    images, ids, mask, answers = O.synthetic_batch(2, seed=1, image_size=64, seq_len=10, vocab=100, num_answers=10)
+    answers[1] = 10
+    tr.step(images.to(DEV), ids.to(DEV), mask.to(DEV), answers.to(DEV))
+    with pytest.raises(IndexError):
+        tr.check()
+    tr.check()                                                    # counter was reset
+    with pytest.raises(RuntimeError):
+        tr.step(images, ids.to(DEV), mask.to(DEV), answers.to(DEV))   # CPU tensor: no silent fallback
+
+
+@pytest.mark.parametrize("clip_active", [True, False])
+@pytest.mark.parametrize("gscale", [1.0, 0.5])
+def test_sumsq_clip_adamw_kernels_match_torch(clip_active, gscale):
+    """vqa_sumsq + vqa_adamw over a flat buffer == clip_grad_norm_(1.0) + torch.optim.AdamW.step on the same numbers, three
+    steps (moments, bias correction), with the 1/world gradient scale of the data-parallel path folded in."""
+    L = sub("_lib")
+    n = 100003
+    g = torch.Generator().manual_seed(17)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * (0.05 if clip_active else 1e-4) for _ in range(3)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    pd, md, vd = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ss = torch.zeros(2049, device=DEV)
+    for t, gr in enumerate(grads, start=1):
+        pr.grad = gr * gscale
+        nrm = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        assert (float(nrm) > 1.0) == clip_active
+        opt.step()
+        gd = gr.to(DEV)
+        L.call("vqa_sumsq", gd.data_ptr(), n, ss.data_ptr())
+        L.call("vqa_adamw", pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.01,
+               1.0 - 0.9 ** t, 1.0 - 0.999 ** t, ss.data_ptr(), 1.0, gscale)
+        torch.cuda.synchronize()
+        assert abs(float(ss[0].sqrt()) * gscale - float(nrm)) / float(nrm) < 1e-5
+        assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6

@@ -18,6 +18,7 @@ P, I, F, D, LL, ULL = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong, 
 # name -> argument ctypes (all return int; last argument is always the stream unless noted)
 SIGNATURES = {
     "vqa_igemm_mtiles": [I, I, I],
+    "vqa_igemm_variant": [I] * 15,
     "vqa_igemm": [I, I, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, P],
     "vqa_wgrad": [I, I, P, P, P] + [I] * 13 + [P],
     "vqa_pack_rows": [I, P, P, I, I, I, P],
@@ -64,12 +65,12 @@ SIGNATURES = {
     "vqa_gate_bwd": [I, P, P, P, P, P, I, I, P],
     "vqa_add": [I, P, P, P, LL, P],
     "vqa_bias_act_bwd": [I, P, P, P, P, I, I, F, ULL, P],
-    "vqa_cross_entropy": [I, P, P, P, P, P, I, I, F, P],
+    "vqa_cross_entropy": [I, P, P, P, P, P, I, I, F, P, P],
     "vqa_convert": [I, I, P, P, LL, P],
     "vqa_sumsq": [P, LL, P, P],
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P],
 }
-_NO_STATUS = {"vqa_igemm_mtiles", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
+_NO_STATUS = {"vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
 
 _lib = None
 

@@ -15,7 +15,8 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h"]]
+    import glob
+    deps = [os.path.join(CSRC, f) for f in SOURCES] + glob.glob(os.path.join(CSRC, "*.h"))     # every header any source includes
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
 // cross entropy (mean) forward+backward in one pass: wave per row
 template <typename T>
 __global__ void cross_entropy_kernel(const T* __restrict__ logits, const long long* __restrict__ targets, float* loss, T* __restrict__ dlogits,
-                                     float* __restrict__ logits_f32, int B, int N, float gscale) {
+                                     float* __restrict__ logits_f32, int B, int N, float gscale, int* err) {
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (row >= B) return;
@@ -395,13 +395,20 @@ __global__ void cross_entropy_kernel(const T* __restrict__ logits, const long lo
   float s = 0.f;
   for (int c = lane; c < N; c += 64) s += expf(to_f<T>(lr[c]) - m);
   s = wave_sum(s);
-  const int t = (int)targets[row];
+  const long long t64 = targets[row];
+  // a target outside [0, N) raises in the reference (nn.CrossEntropyLoss, training/train.py:120): never read out of bounds,
+  // count the row in *err (the host mirror raises from it) and poison its loss term and gradient row with NaN
+  const bool bad = t64 < 0 || t64 >= (long long)N;
+  const int t = bad ? 0 : (int)t64;
   const float lse = m + logf(s);
-  if (lane == 0 && loss) atomicAdd(loss, (lse - to_f<T>(lr[t])) / (float)B);
+  if (lane == 0) {
+    if (loss) atomicAdd(loss, bad ? __builtin_nanf("") : (lse - to_f<T>(lr[t])) / (float)B);
+    if (bad && err) atomicAdd(err, 1);
+  }
   for (int c = lane; c < N; c += 64) {
     const float x = to_f<T>(lr[c]);
     if (logits_f32) logits_f32[(size_t)row * N + c] = x;
-    if (dlogits) dlogits[(size_t)row * N + c] = from_f<T>((expf(x - lse) - (c == t ? 1.f : 0.f)) * gscale / (float)B);
+    if (dlogits) dlogits[(size_t)row * N + c] = from_f<T>(bad ? __builtin_nanf("") : (expf(x - lse) - (c == t ? 1.f : 0.f)) * gscale / (float)B);
   }
 }
 
@@ -569,10 +576,11 @@ int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, 
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_cross_entropy(int dtype, const void* logits, const long long* targets, float* loss, void* dlogits, float* logits_f32, int B, int N,
-                      float gscale, hipStream_t st) {
+                      float gscale, int* err, hipStream_t st) {
+  if (!logits || !targets || B <= 0 || N <= 0) return VQA_EARG;
   dim3 grid((B + 3) / 4);
-  DT(hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, targets, loss, (float*)dlogits, logits_f32, B, N, gscale),
-     hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)logits, targets, loss, (bf16_t*)dlogits, logits_f32, B, N, gscale));
+  DT(hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, targets, loss, (float*)dlogits, logits_f32, B, N, gscale, err),
+     hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)logits, targets, loss, (bf16_t*)dlogits, logits_f32, B, N, gscale, err));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // dtype_in / dtype_out: 0 = f32, 1 = bf16

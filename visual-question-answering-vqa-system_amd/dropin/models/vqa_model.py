@@ -223,6 +223,8 @@ class VQAModel(nn.Module):
                 with torch.cuda.graph(graph):
                     out, _ = self.forward(st_img, st_ids, st_msk)
             g = (graph, st_img, st_ids, st_msk, out)
+            while len(self._graphs) >= self.graph_max_shapes:
+                self._graphs.pop(next(iter(self._graphs)))
             self._graphs[key] = g
         graph, st_img, st_ids, st_msk, out = g
         st_img.copy_(images); st_ids.copy_(token_ids)
@@ -231,10 +233,17 @@ class VQAModel(nn.Module):
         graph.replay()
         return out
 
+    graph_max_batch = 64          # predict() replays a captured HIP graph up to this batch (the serving case, api/inference.py:196-323)
+    graph_max_shapes = 16         # distinct input shapes kept captured (oldest dropped first)
+
     def predict(self, images, token_ids, attention_mask=None, top_k: int = 5):
         self.eval()
         with torch.no_grad():
-            logits, _ = self.forward(images, token_ids, attention_mask)
+            if images.is_cuda and 0 < images.shape[0] <= self.graph_max_batch:
+                # latency mode: ~190 launches of a few microseconds are host-bound at B = 1...64; same kernels, same logits
+                logits = self.forward_graphed(images, token_ids, attention_mask)
+            else:
+                logits, _ = self.forward(images, token_ids, attention_mask)
             probs = F.softmax(logits, dim=-1)
             top_probs, top_indices = probs.topk(top_k, dim=-1)
         return top_indices, top_probs
@@ -268,7 +277,9 @@ def create_vqa_model(vocab_size: int = 10000, num_answers: int = 1000, use_atten
 
 
 def load_vqa_model(checkpoint_path: str, device: str = "cpu") -> VQAModel:
-    checkpoint = torch.load(checkpoint_path, map_location=device, weights_only=False)
+    # the checkpoint dict of training/train.py:280-288 holds tensors, a config dict and scalars only: the weights-only loader
+    # (executes nothing from the file) reads it
+    checkpoint = torch.load(checkpoint_path, map_location=device, weights_only=True)
     model = VQAModel(**checkpoint.get("config", {}))
     model.load_state_dict(checkpoint["model_state_dict"])
     return model.to(device)

@@ -3,9 +3,9 @@
 `HipEngine.forward` replays VQAModel.forward (reference models/vqa_model.py:243-311) as a fixed sequence of
 C-ABI kernel launches on the current stream and records a tape; `HipEngine.backward` walks the tape in
 reverse, writing every parameter gradient into a flat fp32 gradient buffer (same layout as the parameters)
-and calling `on_segment(name)` after each group of layers has enqueued its last gradient kernel
+and calling `on_segment(name, events)` after each group of layers has enqueued its last gradient kernel
 (answer_head, fusion, text_encoder, stage4 ... stem) so a data-parallel driver can start that bucket's
-RCCL all-reduce while earlier layers are still running.
+RCCL all-reduce (on its own stream, after `events`) while earlier layers are still running.
 """
 from __future__ import annotations
 
@@ -29,7 +29,12 @@ class HipEngine:
         self.flat = flat
         self.buf = buffers
         self.dtype = compute_dtype
+        # dropout seeds: (seed_base + step_id) * 4096 + site.  step_id advances on EVERY training forward (so the reference's
+        # unchanged loop model(...) -> loss.backward() -> optimizer.step() draws fresh masks each step); the seeds of a forward
+        # are stored in its tape, so its backward regenerates exactly those masks.  Data-parallel replicas mix their rank in.
         self.seed_base = 0x5EED
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.seed_base += 7919 * torch.distributed.get_rank()
         self.step_id = 0
         self.wsrc = flat
         self._wt: Dict[str, torch.Tensor] = {}
@@ -317,6 +322,8 @@ class HipEngine:
                 want_aux: bool = False, need_tape: bool = True):
         cfg, T = self.cfg, self.dtype
         self._site = 0
+        if training:
+            self.step_id += 1
         self.begin_step(for_backward=need_tape)
         tape: dict = {"training": training, "B": images.shape[0]}
         B, _, IH, IW = images.shape
@@ -596,8 +603,20 @@ class HipEngine:
         cfg, T = self.cfg, self.dtype
         training = tape["training"]
         B = tape["B"]
-        seg = on_segment or (lambda name: None)
         self._deferred = []                       # (a backward that raised must not leak its held-back launches into this one)
+
+        def seg(name):
+            """Report a finished gradient segment.  The bucket may be all-reduced once everything enqueued so far on the CURRENT
+            stream and on the weight-gradient side stream has run: hand both events to the reducer (its communication stream
+            waits for them); the compute streams themselves are NOT joined, so the data-gradient chain is never held back."""
+            if on_segment is None:
+                return
+            evs = []
+            cur = torch.cuda.current_stream()
+            e = torch.cuda.Event(); e.record(cur); evs.append(e)
+            if self.wgrad_stream and self.two_streams and self.side2 is not None:
+                e2 = torch.cuda.Event(); e2.record(self.side2); evs.append(e2)
+            on_segment(name, evs)
         dl = dlogits.to(T).contiguous() if dlogits.dtype != T else dlogits.contiguous()
 
         # ---- head
@@ -681,13 +700,32 @@ class HipEngine:
                 dxc = dxn
             for rec in reversed(srec["blocks"]):
                 dxc = self._block_bwd(rec, dxc, G, training)
-            if on_segment is not None:
-                self._join_off_path()
-            seg(f"image_encoder.stage{s}")
+            if not self._deferred:                # stage 1: its held-back weight gradients are released below, report it there
+                seg(f"image_encoder.stage{s}")
 
         # ---- stem
+        self._stem_bwd(tape, dxc, G, training, after_reduce=lambda: (self._flush_deferred_and_report(seg)))
+        seg("image_encoder.stem")
+        self._join_off_path()
+        if use_side:
+            main.wait_event(ev_tb)
+
+    def _flush_deferred_and_report(self, seg):
+        had_deferred = bool(self._deferred)
+        self._flush_deferred()
+        if had_deferred:
+            seg("image_encoder.stage1")
+
+    def _stem_bwd(self, tape, dxc, G, training, after_reduce=None, fused=None):
+        """Backward of conv7x7/2 -> BN -> ReLU -> MaxPool3x3/2 (models/cnn_backbone.py:349-354) given dxc = gradient of the
+        pooled output [B*Hp*Wp, 64].  fused=None picks the fused weight-gradient kernel whenever the dedicated bf16 stem path
+        is active; fused=False forces the two-launch path (BN/ReLU/pool backward materialised, then the generic wgrad)."""
+        T = self.dtype
+        B = tape["B"]
         st = tape["stem"]
         Bq, IH, IW, _, H1, W1 = st["geom"][:6]
+        if fused is None:
+            fused = self.stem_w2 is not None and K.stem_conv_blocks(B, IH, IW) > 0
         # BatchNorm-backward sums of the stem WITHOUT touching the 112x112 tensors: every pooling window routes its gradient to
         # exactly one position (its argmax), whose post-ReLU value is the pooled output itself, so
         #   sum g       = sum_windows dpool * [pooled > 0]
@@ -706,8 +744,9 @@ class HipEngine:
         bnp = "image_encoder.stem.1"
         call("vqa_bn_bwd_finalize", ptr(slab), nb, 64, 1, float(B * H1 * W1), ptr(self.P(bnp + ".weight")), ptr(st["coef"]),
              int(training), ptr(self._gslice(G, bnp + ".weight")), ptr(self._gslice(G, bnp + ".bias")), ptr(bc))
-        self._flush_deferred()                    # stage-1 block-0 weight gradients run beside the stem weight gradient
-        if self.stem_w2 is not None and K.stem_conv_blocks(B, IH, IW) > 0:
+        if after_reduce is not None:
+            after_reduce()                        # stage-1 block-0 weight gradients run beside the stem weight gradient
+        if fused:
             # dy (B x 112 x 112 x 64) is never written: the weight-gradient kernel rebuilds it row by row
             dwv = self._gslice(G, "image_encoder.stem.0.weight")
             if K.PROFILE is not None:
@@ -721,10 +760,6 @@ class HipEngine:
             call("vqa_stem_bwd_apply", dt(T), ptr(dxc), ptr(st["idx"]), ptr(st["y"]), ptr(st["coef"]), ptr(bc), ptr(dy), B, H1, W1, 64)
             K.wgrad(dy, st["images"], LY.mat_of(G, self.E["image_encoder.stem.0.weight"]), B * H1 * W1, 64, 147, st["geom"], dtype=T,
                     loader=K.LOADER_STEM)
-        seg("image_encoder.stem")
-        self._join_off_path()
-        if use_side:
-            main.wait_event(ev_tb)
 
     def _block_bwd(self, rec, dout, G, training):
         """ResidualBlock backward (reference forward: models/cnn_backbone.py:164-197)."""

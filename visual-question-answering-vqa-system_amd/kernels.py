@@ -21,13 +21,25 @@ LOADER_NHWC, LOADER_STEM = 0, 1
 PROFILE = None
 
 
-def _tile(M, N, loader):
-    if loader == LOADER_STEM:
-        return 128, 64
-    bm, bn = (128, 64) if N <= 64 else (128, 128)
-    if ((M + bm - 1) // bm) * ((N + bn - 1) // bn) < 384:
-        bm, bn = 64, 64
-    return bm, bn
+def igemm_variant(dtype, loader, M, N, Kw, geom) -> int:
+    """The template instantiation the C dispatch (gemm_conv.hip igemm_variant) picks: BM*10000 + BN*10 + flavour."""
+    B, H, W, C, Ho, Wo, R, S, stride, pad = geom
+    return L.count("vqa_igemm_variant", dt(dtype), loader, M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad)
+
+
+def igemm_symbol(dtype, loader, var) -> str:
+    """Kernel symbol as rocprofv3 prints it: igemm_kernel<T, BM, BN, LOADER, waves, BK, waves/SIMD, ring slots, window loader>."""
+    bm, bn, fl = var // 10000, (var % 10000) // 10, var % 10
+    nw, bk, occ, st, win = 4, _bk(dtype), 2, 2, 0
+    if fl == 1:
+        win = 1
+    elif fl in (2, 3):
+        nw, st = 8, fl
+    elif fl == 4:
+        nw, bk = 2, 32
+    elif fl == 5:
+        bk, occ = 32, 3
+    return f"igemm_kernel<{_tname(dtype)}, {bm}, {bn}, {loader}, {nw}, {bk}, {occ}, {st}, {win}>"
 
 
 def _tname(dtype):
@@ -153,16 +165,12 @@ def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=
          M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad, transposed, relu, float(drop_p), int(drop_seed))
     if PROFILE is not None:
         e1.record()
-        bm, bn = _tile(M, N, loader)
+        var = igemm_variant(dtype, loader, M, N, Kw, geom)
         kreal = 147 if loader == LOADER_STEM else Kw
         flops = 2.0 * B * H * W * C * R * S * N if transposed else 2.0 * M * N * kreal
         es = 2 if dtype == torch.bfloat16 else 4
         nbytes = (B * H * W * C * (4 if loader == LOADER_STEM else es)) + (M * N + N * Kw) * es
-        # exact template instantiation the C dispatch picks (gemm_conv.hip igemm_dispatch), so that the live timing, the rocprofv3
-        # summary and the PMC traffic table name the same symbol: <T, BM, BN, LOADER, waves, BK, waves/SIMD, ring slots, window loader>
-        win = int(dtype == torch.bfloat16 and loader == LOADER_NHWC and R == 3 and S == 3 and stride == 1 and pad == 1 and H == Ho
-                  and W == Wo and C % 64 == 0 and bm == 128 and os.environ.get("VQA_IGEMM_WIN", "1") != "0")
-        PROFILE.append((f"igemm_kernel<{_tname(dtype)}, {bm}, {bn}, {loader}, 4, {_bk(dtype)}, 2, 2, {win}>", flops, e0, e1, nbytes))
+        PROFILE.append((igemm_symbol(dtype, loader, var), flops, e0, e1, nbytes))
     return out, stats, mt
 
 

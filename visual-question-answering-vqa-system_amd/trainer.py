@@ -33,7 +33,11 @@ class GradBucketReducer:
         self._works: List = []
         self.issued: List[str] = []
 
-    def on_segment(self, name: str):
+    def on_segment(self, name: str, events=()):
+        """`events`: HIP events after which every gradient kernel of this segment has been enqueued-and-ordered (the engine
+        records one on each stream that wrote the bucket: the data-gradient stream and the weight-gradient side stream).
+        Only the COMMUNICATION stream waits for them -- the compute streams are never joined here, so the data-gradient chain
+        keeps running ahead of the weight gradients exactly as in the 1-GPU step."""
         if self.world == 1 or name not in self._range:
             return
         lo, hi = self._range[name]
@@ -44,8 +48,14 @@ class GradBucketReducer:
             ev.record()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                for e in events:
+                    self.comm_stream.wait_event(e)
                 self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
+            if self.G.is_cuda:
+                cur = torch.cuda.current_stream()
+                for e in events:
+                    cur.wait_event(e)
             self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
@@ -69,6 +79,7 @@ class HipTrainer:
         self.v = torch.zeros_like(flat)
         self.sumsq = torch.zeros(1 + 2048, device=flat.device, dtype=torch.float32)   # [0] = sum of squares, rest: block partials
         self.loss = torch.zeros(1, device=flat.device, dtype=torch.float32)
+        self.bad_targets = torch.zeros(1, device=flat.device, dtype=torch.int32)   # rows whose target was outside [0, num_answers)
         self.t = 0
         self.buckets = LY.bucket_ranges(model._entries)
         self.reducer = GradBucketReducer(self.G, self.buckets, process_group, overlap)
@@ -78,13 +89,24 @@ class HipTrainer:
         """One full train step; returns (loss device scalar, logits fp32).  `metrics`: optional device-side accuracy tracker
         (dropin/utils/metrics.py VQAAccuracy) updated from the logits without a host sync (train.py:211-212 does two)."""
         eng, T = self.engine, self.engine.dtype
+        dev = self.G.device
+        for name, t in (("images", images), ("token_ids", token_ids), ("targets", targets)):
+            if not (isinstance(t, torch.Tensor) and t.device == dev):
+                raise RuntimeError(f"HipTrainer.step: `{name}` must be a tensor on {dev} (there is no CPU path)")
+        if images.dim() != 4 or images.shape[1] != 3 or token_ids.dim() != 2 or token_ids.shape[0] != images.shape[0] \
+                or targets.shape != (images.shape[0],):
+            raise RuntimeError("HipTrainer.step: expected images [B,3,H,W], token_ids [B,L], targets [B]")
+        # the kernels read raw pointers: enforce the dtypes / contiguity VQAModel.forward enforces (vqa_model.py drop-in)
+        images = images.contiguous().float()
+        token_ids = token_ids.contiguous().long()
+        targets = targets.contiguous().long()
         self.G.zero_()
         self.loss.zero_()
-        maskf = None if attention_mask is None else attention_mask.float()
+        maskf = None if attention_mask is None else attention_mask.contiguous().float()
         logits_f, _, tape = eng.forward(images, token_ids, maskf, True, False, need_tape=True)
         B, N = logits_f.shape
         dlogits = torch.empty((B, N), device=images.device, dtype=torch.float32)
-        call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0)
+        call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0, ptr(self.bad_targets))
         if metrics is not None:
             metrics.update(logits_f, targets)
         eng.backward(tape, dlogits, self.G, on_segment=self.reducer.on_segment if self.world > 1 else None)
@@ -94,8 +116,15 @@ class HipTrainer:
         b1, b2 = self.betas
         call("vqa_adamw", ptr(self.model._flat), ptr(self.G), ptr(self.m), ptr(self.v), self.G.numel(), self.lr, b1, b2, self.eps,
              self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, ptr(self.sumsq), float(self.max_norm), gscale)
-        eng.step_id += 1
         return self.loss, logits_f
 
     def grad_norm(self) -> torch.Tensor:
         return self.sumsq[:1].sqrt() / self.world
+
+    def check(self):
+        """Host-side error check (one sync; call it per logging interval, not per step): raises like nn.CrossEntropyLoss does
+        (training/train.py:120) if any step since the last check saw a target outside [0, num_answers)."""
+        n = int(self.bad_targets.item())
+        if n:
+            self.bad_targets.zero_()
+            raise IndexError(f"{n} target(s) out of range [0, {self.model.num_answers}) since the last check (loss and gradients are NaN)")
