@@ -48,6 +48,14 @@ def test_fused_stem_wgrad_equals_two_launch_path_b64():
 
 @pytest.mark.parametrize("B", [4])
 def test_fused_stem_wgrad_matches_oracle_autograd_224(B):
+    """Two references at 224x224:
+    (1) SHARP: autograd of the oracle's BN -> ReLU -> MaxPool (oracle.batchnorm2d = nn.BatchNorm2d train mode) applied to the
+        conv output the HIP forward actually stored (bf16 y), then torch's conv weight gradient on the bf16-rounded image.
+        ReLU signs and pooling winners are then decided on the same numbers as in the kernel: 1e-2 of the largest |dW|.
+    (2) END TO END: autograd of oracle.stem() from the image.  Its fp32 conv output breaks pooling near-ties differently from
+        the 8-bit-mantissa y (about 1 % of the windows route their gradient to a neighbouring pixel), which is noise of the
+        bf16 storage format, not of the kernel: 15 % of the largest element, gradient norm within 2 %."""
+    import torch.nn.functional as F
     m, eng, tape, sd, images = _engine_after_forward(B, seed=32)
     g = torch.Generator().manual_seed(6)
     dpool = torch.randn(B, 64, 56, 56, generator=g).to(torch.bfloat16).float()
@@ -57,19 +65,29 @@ def test_fused_stem_wgrad_matches_oracle_autograd_224(B):
     torch.cuda.synchronize()
     K = sub("kernels")
     assert eng.stem_w2 is not None and K.stem_conv_blocks(B, 224, 224) > 0
-    sdr = {k: v.clone() for k, v in sd.items()}
     wn = "image_encoder.stem.0.weight"
-    sdr[wn] = sd[wn].to(torch.bfloat16).float().requires_grad_(True)
-    for k in ("image_encoder.stem.1.weight", "image_encoder.stem.1.bias"):
-        sdr[k] = sd[k].clone().requires_grad_(True)
-    pooled = O.stem(images.to(torch.bfloat16).float(), sdr, True, {})
-    pooled.backward(dpool)
     e = eng.E[wn]
     got = G[e.offset: e.offset + e.numel].view(64, 7, 7, 3).cpu()
-    ref = sdr[wn].grad.permute(0, 2, 3, 1)
-    # bf16 y (8-bit mantissa) decides ReLU signs / pooling argmax near ties and enters xhat: 2e-2 of the largest |dW| element
-    assert _relerr(got, ref) < 2e-2
-    assert abs(float(got.norm()) - float(ref.norm())) / float(ref.norm()) < 5e-3
+    img_r = images.to(torch.bfloat16).float()
+
+    # (1) from the stored y
+    y_leaf = tape["stem"]["y"].float().cpu().view(B, 112, 112, 64).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    sd1 = {k: v.clone() for k, v in sd.items()}
     for k in ("image_encoder.stem.1.weight", "image_encoder.stem.1.bias"):
-        e = eng.E[k]
-        assert _relerr(G[e.offset: e.offset + e.numel].cpu(), sdr[k].grad) < 2e-2, k
+        sd1[k] = sd[k].clone().requires_grad_(True)
+    pooled1 = F.max_pool2d(torch.relu(O.batchnorm2d(y_leaf, sd1, "image_encoder.stem.1", True, None)), 3, 2, 1)
+    pooled1.backward(dpool)
+    dw1 = torch.nn.grad.conv2d_weight(img_r, (64, 3, 7, 7), y_leaf.grad, stride=2, padding=3).permute(0, 2, 3, 1)
+    assert _relerr(got, dw1) < 1e-2
+    for k in ("image_encoder.stem.1.weight", "image_encoder.stem.1.bias"):
+        ek = eng.E[k]
+        assert _relerr(G[ek.offset: ek.offset + ek.numel].cpu(), sd1[k].grad) < 1e-2, k
+
+    # (2) from the image
+    sdr = {k: v.clone() for k, v in sd.items()}
+    sdr[wn] = sd[wn].to(torch.bfloat16).float().requires_grad_(True)
+    pooled = O.stem(img_r, sdr, True, {})
+    pooled.backward(dpool)
+    ref = sdr[wn].grad.permute(0, 2, 3, 1)
+    assert _relerr(got, ref) < 0.15
+    assert abs(float(got.norm()) - float(ref.norm())) / float(ref.norm()) < 2e-2

@@ -89,8 +89,8 @@ def test_three_steps_track_the_oracle_trainer():
         assert err <= 0.15 * moved + 1e-7, (n, err, moved)
     st = m.state_dict()
     for k, v in ot.sd.items():
-        if "running_" in k:
-            assert (st[k].cpu() - v).abs().max().item() < 1e-4, k
+        if "running_" in k:      # (weights have moved ~3e-3 per element by now, a few of them in different directions: see above)
+            assert (st[k].cpu() - v).abs().max().item() < 5e-3 * max(1.0, float(v.abs().max())), k
     assert int(st["image_encoder.stem.1.num_batches_tracked"]) == 3
     assert tr.t == 3
 
