@@ -35,9 +35,15 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
               const void* addmask, float* stats, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
               hipStream_t stream);
-/* dw[N][Kw] += dy[M][N]^T * gather(x)[M][Kw]   (split over M, fp32 atomics) */
+/* dw[N][Kw] += dy[M][N]^T * gather(x)[M][Kw], split over the M pixels.
+ * With a workspace (`ws`, caller-owned scratch of >= the ws_floats vqa_wgrad_plan reports; contents undefined afterwards) every
+ * split writes its fp32 tile to its own slab and a second launch adds the slabs to dw in a FIXED order: dw is bit-reproducible,
+ * no float atomics.  ws == NULL (or too small): fp32 atomics.  vqa_wgrad_plan is a host-only query: *kind 1 = the 8-wave LDS-DMA
+ * kernel (bf16, the large CNN convs), 0 = the 4-wave kernel; tile, split count, workspace floats (0 = single split, no reduce). */
+int vqa_wgrad_plan(int dtype, int loader, int M, int N, int Kw, int B, int H, int W, int C, int R, int S, long long* ws_floats,
+                   int* kind, int* tile_n, int* tile_k, int* nsplit);
 int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw, int M, int N, int Kw, int B, int H, int W,
-              int C, int Ho, int Wo, int R, int S, int stride, int pad, hipStream_t stream);
+              int C, int Ho, int Wo, int R, int S, int stride, int pad, float* ws, long long ws_floats, hipStream_t stream);
 int vqa_pack_rows(int dtype, const float* in, void* out, int N, int K, int Kp, hipStream_t stream);          /* cast + row pad   */
 int vqa_pack_transpose(int dtype, const float* in, void* out, int N, int T, int C, int ldo, int col0, int flip, hipStream_t stream); /* out[c][col0+t*N+n] = in[n][flip?T-1-t:t][c] */
 int vqa_pack_transpose_batch(int dtype, const float* flat, void* out, const long long* desc, int nd, int total_blocks, hipStream_t stream); /* nd pieces, device table desc[nd][10] = {src_off, dst_off, N, T, C, ldo, col0, flip, blk0, 0}, blk0 = running sum of T*ceil(N/32)*ceil(C/32): every data-gradient operand of a step in one launch */

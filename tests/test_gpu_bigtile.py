@@ -138,3 +138,32 @@ def test_token_side_wgrad_at_benchmark_rows():
         K.wgrad(dy.to(DEV, BF), x.to(DEV, BF), dw, M, N, Kin, K.linear_geom(M, Kin), dtype=BF)
         torch.cuda.synchronize()
         assert _relerr(dw.cpu(), dy.t() @ x) < 3e-3, (M, Kin, N)
+
+
+def test_weight_gradients_are_bit_reproducible():
+    """Two-pass split (per-split slabs + fixed-order reduce) instead of float atomics: the same launch twice gives the SAME bits,
+    for the 8-wave LDS-DMA kernel (stage-3 conv), the 4-wave kernel (stage-2 conv, token-side Linear) and fp32."""
+    K = sub("kernels")
+    g = torch.Generator().manual_seed(21)
+    cases = [(256, 256, 256, 14, 3, BF, 1), (64, 128, 128, 28, 3, BF, 0), (64, 128, 128, 28, 3, torch.float32, 0)]
+    for B, Cin, Cout, H, R, dtype, want_kind in cases:
+        x = torch.randn(B * H * H, Cin, generator=g).to(DEV, dtype)
+        dy = torch.randn(B * H * H, Cout, generator=g).to(DEV, dtype)
+        M, Kw = B * H * H, R * R * Cin
+        geom = (B, H, H, Cin, H, H, R, R, 1, 1)
+        kind, tn, tk, nsplit, wsf = K.wgrad_plan(dtype, K.LOADER_NHWC, M, Cout, Kw, B, H, H, Cin, R, R)
+        assert kind == want_kind and nsplit > 1 and wsf == nsplit * Cout * Kw
+        outs = []
+        for _ in range(3):
+            dw = torch.zeros(Cout, Kw, device=DEV)
+            K.wgrad(dy, x, dw, M, Cout, Kw, geom, dtype=dtype)
+            torch.cuda.synchronize()
+            outs.append(dw)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    M, Kin, N = 10240, 256, 768
+    x = torch.randn(M, Kin, generator=g).to(DEV, BF); dy = torch.randn(M, N, generator=g).to(DEV, BF)
+    a, b = torch.zeros(N, Kin, device=DEV), torch.zeros(N, Kin, device=DEV)
+    K.wgrad(dy, x, a, M, N, Kin, K.linear_geom(M, Kin), dtype=BF)
+    K.wgrad(dy, x, b, M, N, Kin, K.linear_geom(M, Kin), dtype=BF)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)

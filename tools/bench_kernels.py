@@ -74,3 +74,13 @@ if not args.only or "stem" in args.only:
     fl = 2.0 * B * 112 * 112 * 64 * 147
     t = timeit(lambda: K.stem_wgrad(img, dy, dw, B, H, H), args.iters)
     print(f"stem wgrad (unfused)   {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   io {(img.numel()*4+dy.numel()*2)/t/1e12:5.2f} TB/s")
+
+if not args.only or "tok" in args.only:
+    # token-side weight gradients of a B=512 step: (rows, K in, N out)
+    for M, Kin, N in ((10240, 256, 768), (10240, 256, 256), (10240, 256, 1024), (10240, 1024, 256), (25088, 512, 256), (25088, 256, 512),
+                      (25088, 256, 256), (512, 512, 256), (512, 256, 512), (512, 256, 1000)):
+        x = torch.randn(M, Kin, device=dev).to(T)
+        dy = torch.randn(M, N, device=dev).to(T)
+        dw = torch.zeros(N, Kin, device=dev)
+        t = timeit(lambda: K.wgrad(dy, x, dw, M, N, Kin, K.linear_geom(M, Kin), dtype=T), args.iters)
+        print(f"tok wgrad M={M:6d} K={Kin:5d} N={N:5d}  {t*1e6:8.1f} us {2.0*M*N*Kin/t/1e12:7.1f} TF/s  plan {K.wgrad_plan(T, 0, M, N, Kin, M, 1, 1, Kin, 1, 1)}")

@@ -20,7 +20,8 @@ SIGNATURES = {
     "vqa_igemm_mtiles": [I, I, I],
     "vqa_igemm_variant": [I] * 15,
     "vqa_igemm": [I, I, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, P],
-    "vqa_wgrad": [I, I, P, P, P] + [I] * 13 + [P],
+    "vqa_wgrad_plan": [I] * 11 + [P, P, P, P, P],
+    "vqa_wgrad": [I, I, P, P, P] + [I] * 13 + [P, LL, P],
     "vqa_pack_rows": [I, P, P, I, I, I, P],
     "vqa_pack_transpose": [I, P, P, I, I, I, I, I, I, P],
     "vqa_pack_transpose_batch": [I, P, P, P, I, I, P],

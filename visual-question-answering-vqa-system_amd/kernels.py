@@ -174,21 +174,36 @@ def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=
     return out, stats, mt
 
 
+_PLAN_CACHE = {}
+
+
+def wgrad_plan(dtype, loader, M, N, Kw, B, H, W, C, R, S):
+    """(kind, tile_n, tile_k, nsplit, workspace floats) of vqa_wgrad for this problem; kind 1: the 8-wave LDS-DMA kernel."""
+    key = (dtype, loader, M, N, Kw, B, H, W, C, R, S)
+    pl = _PLAN_CACHE.get(key)
+    if pl is None:
+        import ctypes as C_
+        wsf, kind, tn, tk, ns = C_.c_longlong(0), C_.c_int(0), C_.c_int(0), C_.c_int(0), C_.c_int(0)
+        L.lib().vqa_wgrad_plan(dt(dtype), loader, M, N, Kw, B, H, W, C, R, S, C_.byref(wsf), C_.byref(kind), C_.byref(tn), C_.byref(tk),
+                               C_.byref(ns))
+        pl = _PLAN_CACHE[key] = (kind.value, tn.value, tk.value, ns.value, wsf.value)
+    return pl
+
+
 def wgrad(dy, x, dw, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC):
-    """dw[N][Kw] (fp32) += dy[M][N]^T @ gather(x)[M][Kw]."""
+    """dw[N][Kw] (fp32) += dy[M][N]^T @ gather(x)[M][Kw]: deterministic two-pass split (workspace slabs + fixed-order reduce)."""
     B, H, W, C, Ho, Wo, R, S, stride, pad = geom
+    kind, tn, tk, nsplit, wsf = wgrad_plan(dtype, loader, M, N, Kw, B, H, W, C, R, S)
+    ws = torch.empty(wsf, device=dy.device, dtype=torch.float32) if wsf else None       # torch's caching allocator, stream-ordered
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("vqa_wgrad", dt(dtype), loader, ptr(dy), ptr(x), ptr(dw), M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad)
+    call("vqa_wgrad", dt(dtype), loader, ptr(dy), ptr(x), ptr(dw), M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad, ptr(ws), wsf)
     if PROFILE is not None:
         e1.record()
-        big = N >= 128 and ((C % 128 == 0) if R * S > 1 else (Kw >= 128)) and loader == LOADER_NHWC
-        mid = (not big) and loader == LOADER_NHWC and N >= 128 and ((C % 64 == 0) if R * S > 1 else (Kw >= 64))
-        t, t2 = (128 if (big or mid) else 64), (128 if big else 64)
         es = 2 if dtype == torch.bfloat16 else 4
-        PROFILE.append((f"wgrad_kernel<{_tname(dtype)}, {t}, {t2}, {loader}>", 2.0 * M * N * Kw, e0, e1,
-                        (M * N + B * H * W * C) * es + N * Kw * 4))
+        name = f"wgrad_dma_kernel<{tn}, {tk}, 2>" if kind else f"wgrad_kernel<{_tname(dtype)}, {tn}, {tk}, {loader}>"     # (timing includes the reduce launch)
+        PROFILE.append((name, 2.0 * M * N * Kw, e0, e1, (M * N + B * H * W * C) * es + N * Kw * 4))
 
 
 def linear_geom(M, K):
