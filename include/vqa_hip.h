@@ -58,7 +58,10 @@ int vqa_fold_bn_batch(int dtype, const float* flat, void* wout, float* bout, con
 int vqa_conv3x3_c64_blocks(int B, int H, int W);
 int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const void* addend, const void* addmask,
                     int B, int H, int W, hipStream_t stream);
-int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw /* [64][576] += */, int B, int H, int W, hipStream_t stream);
+int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw /* [64][576] += */, int B, int H, int W,
+                     float* ws /* >= vqa_conv3x3_c64_blocks * 64*576 floats of scratch, or NULL: atomics */, long long ws_floats, hipStream_t stream);
+/* second pass of the deterministic split weight gradients: dw[i] += sum_s ws[s][i] in slab order (n % 4 == 0) */
+int vqa_slab_reduce(const float* ws, float* dw, int nslabs, long long n, hipStream_t stream);
 /* data gradient of a stride-2 conv (+ the block's 1x1/2 shortcut, models/cnn_backbone.py:243-247) in one launch; rows are
  * grouped by output parity class so only the valid taps are issued.  dy/dyd [B][H][W][C], out [B][Ho=2H][Wo=2W][N] */
 int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, void* out, int B, int H, int W, int C,
@@ -67,10 +70,12 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
 int vqa_stem_conv_blocks(int B, int H, int W);
 int vqa_stem_pack(const float* w_krsc, void* wstem, hipStream_t stream);
 int vqa_stem_conv(const float* img, const void* wstem, void* out, float* stats, int B, int H, int W, hipStream_t stream);
-int vqa_stem_wgrad(const float* img, const void* dy, float* dw /* [64][7][7][3] += */, int B, int H, int W, hipStream_t stream);
+int vqa_stem_wgrad_blocks(int B, int H, int W);   /* workgroups of the two stem weight-gradient kernels; their scratch: blocks * 64*147 floats */
+int vqa_stem_wgrad(const float* img, const void* dy, float* dw /* [64][7][7][3] += */, int B, int H, int W,
+                   float* ws /* scratch or NULL: atomics */, long long ws_floats, hipStream_t stream);
 /* same, with the stem BN+ReLU+MaxPool backward apply fused in: dy is rebuilt per row from y, dpool, idx, coef, bcoef */
 int vqa_stem_wgrad_fused(const float* img, const void* y, const void* dpool, const uint8_t* idx, const float* coef,
-                         const float* bcoef, float* dw, int B, int H, int W, hipStream_t stream);
+                         const float* bcoef, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t stream);
 
 /* ---- BatchNorm2d (nn.BatchNorm2d defaults; models/cnn_backbone.py:151,158,246,351) -----------------------------
  * coef = scale | shift | mean | invstd (4*C floats).  finalize also updates running_mean/var (momentum, unbiased var)

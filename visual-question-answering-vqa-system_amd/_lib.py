@@ -28,13 +28,15 @@ SIGNATURES = {
     "vqa_fold_bn_batch": [I, P, P, P, P, I, I, F, P],
     "vqa_conv3x3_c64_blocks": [I, I, I],
     "vqa_conv3x3_c64": [P, P, P, P, P, P, I, I, I, P],
-    "vqa_wgrad3x3_c64": [P, P, P, I, I, I, P],
+    "vqa_wgrad3x3_c64": [P, P, P, I, I, I, P, LL, P],
+    "vqa_slab_reduce": [P, P, I, LL, P],
     "vqa_dgrad_s2": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "vqa_stem_conv_blocks": [I, I, I],
     "vqa_stem_pack": [P, P, P],
     "vqa_stem_conv": [P, P, P, P, I, I, I, P],
-    "vqa_stem_wgrad": [P, P, P, I, I, I, P],
-    "vqa_stem_wgrad_fused": [P, P, P, P, P, P, P, I, I, I, P],
+    "vqa_stem_wgrad_blocks": [I, I, I],
+    "vqa_stem_wgrad": [P, P, P, I, I, I, P, LL, P],
+    "vqa_stem_wgrad_fused": [P, P, P, P, P, P, P, I, I, I, P, LL, P],
     "vqa_bn_stats_finalize": [P, I, I, D, P, P, P, P, P, F, F, P, P, P],
     "vqa_bn_eval_coef": [I, P, P, P, P, F, P, P],
     "vqa_bn_apply": [I, P, P, P, P, P, LL, I, I, P],
@@ -71,7 +73,7 @@ SIGNATURES = {
     "vqa_sumsq": [P, LL, P, P],
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P],
 }
-_NO_STATUS = {"vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
+_NO_STATUS = {"vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
 
 _lib = None
 

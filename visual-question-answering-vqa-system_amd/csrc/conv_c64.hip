@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(C64Params p) {
 // ------------------------------------------------------------------------------------------------
 // weight gradient: dw[n][(r,s,c)] += sum_px dy[px][n] * x[px + (r-1, s-1)][c]
 // ------------------------------------------------------------------------------------------------
-struct C64WgradParams { const bf16_t* x; const bf16_t* dy; float* dw; int B, H, W; unsigned x_bytes, dy_bytes; };
+struct C64WgradParams { const bf16_t* x; const bf16_t* dy; float* dw; float* ws; int B, H, W; unsigned x_bytes, dy_bytes; };
 
 __global__ __launch_bounds__(256) void wgrad3x3_c64_kernel(C64WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -272,15 +272,23 @@ __global__ __launch_bounds__(256) void wgrad3x3_c64_kernel(C64WgradParams p) {
       }
     }
   }
-  // flush: D[i = n][j = c] per tap -> dw[n][(tap*64 + c)]
+  // flush: D[i = n][j = c] per tap -> dw[n][(tap*64 + c)].  With a workspace every workgroup stores its partial dW into its own
+  // slab (vqa_slab_reduce adds the slabs in a fixed order: bit-reproducible, and 512 x 147 KB of float atomics were a quarter of
+  // this kernel's time); without one, fp32 atomics.
+  float* slab = p.ws ? p.ws + (size_t)blockIdx.x * 64 * 576 : nullptr;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-        atomicAdd(p.dw + (size_t)(i * 16 + g * 4 + rr) * 576 + t * 64 + wave * 16 + li, acc[i][t][rr]);
+      for (int rr = 0; rr < 4; ++rr) {
+        const size_t o = (size_t)(i * 16 + g * 4 + rr) * 576 + t * 64 + wave * 16 + li;
+        if (slab) slab[o] = acc[i][t][rr];
+        else atomicAdd(p.dw + o, acc[i][t][rr]);
+      }
 }
+
+extern "C" int vqa_slab_reduce(const float* ws, float* dw, int nslabs, long long n, hipStream_t st);
 
 extern "C" {
 
@@ -309,12 +317,14 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
   hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), shm, st, p);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
-// dw [64][576] fp32 (+=)
-int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int W, hipStream_t st) {
+// dw [64][576] fp32 (+=).  ws: scratch of >= vqa_conv3x3_c64_blocks(B,H,W) * 64*576 floats for the deterministic two-pass
+// accumulation (NULL or too small: fp32 atomics)
+int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t st) {
   const int grid = vqa_conv3x3_c64_blocks(B, H, W);
   if (!x || !dy || !dw || grid <= 0) return VQA_EARG;
   C64WgradParams p;
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.B = B; p.H = H; p.W = W;
+  p.ws = (ws && ws_floats >= (long long)grid * 64 * 576) ? ws : nullptr;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)xb;
@@ -323,7 +333,8 @@ int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int
   static size_t attr = 0;
   if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
   hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(grid), dim3(256), shm, st, p);
-  VQA_LAUNCH_CHECK(); return VQA_OK;
+  VQA_LAUNCH_CHECK();
+  return p.ws ? vqa_slab_reduce(p.ws, dw, grid, 64 * 576, st) : VQA_OK;
 }
 
 }  // extern "C"

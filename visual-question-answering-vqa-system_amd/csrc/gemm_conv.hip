@@ -1535,6 +1535,16 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
   return p.ws ? launch_reduce(p, ns, st) : VQA_OK;
 }
 
+// dw[i] += sum_{s < nslabs} ws[s][i], i < n (n % 4 == 0), slabs added in index order: the second pass of every deterministic
+// split weight gradient (vqa_wgrad calls it itself; the stage-1 patch kernel and the stem kernels use it through this entry)
+int vqa_slab_reduce(const float* ws, float* dw, int nslabs, long long n, hipStream_t st) {
+  if (!ws || !dw || nslabs <= 0 || n <= 0 || (n % 4)) return VQA_EARG;
+  const size_t total4 = (size_t)n / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, ws, dw, nslabs, total4);
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
+}
+
 // out[N][Kp] (T) = cast(in[N][K] fp32), zero padded rows
 int vqa_pack_rows(int dtype, const float* in, void* out, int N, int K, int Kp, hipStream_t st) {
   if (!in || !out || N <= 0 || K <= 0 || Kp < K) return VQA_EARG;

@@ -149,7 +149,7 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                                                          int B, int H, int W, int Ho, int Wo, const bf16_t* __restrict__ dpool,
                                                          const uint8_t* __restrict__ idx, const float* __restrict__ coef,
-                                                         const float* __restrict__ bc, int Hp, int Wp, int nsplit) {
+                                                         const float* __restrict__ bc, int Hp, int Wp, int nsplit, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PW = 2 * Wo + 8;
   const int Wh = Wo / nsplit;                                        // pixels per unit: a row is contracted in nsplit pieces so that
@@ -268,9 +268,27 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-        atomicAdd(dw + (size_t)(i * 16 + g * 4 + rr) * 147 + (r * 7 + s) * 3 + c, acc[i][j][rr]);
+      for (int rr = 0; rr < 4; ++rr) {
+        const size_t o = (size_t)(i * 16 + g * 4 + rr) * 147 + (r * 7 + s) * 3 + c;
+        // with a workspace: this workgroup's own [64][147] slab (every element exactly once), summed later in a fixed order
+        if (ws) ws[(size_t)blockIdx.x * (64 * 147) + o] = acc[i][j][rr];
+        else atomicAdd(dw + o, acc[i][j][rr]);
+      }
   }
+}
+
+extern "C" int vqa_slab_reduce(const float* ws, float* dw, int nslabs, long long n, hipStream_t st);
+
+static int stem_wgrad_grid(int B, int Ho, int Wo, size_t* shm_out) {
+  int nsplit = Wo > 64 ? 2 : 1;
+  { static int env = -1; if (env < 0) { const char* e = getenv("VQA_STEM_NSPLIT"); env = e ? atoi(e) : 0; } if (env > 0 && Wo % (8 * env) == 0) nsplit = env; }
+  const int PW = 2 * Wo + 8, MP = (Wo / nsplit + 31) / 32 * 32;
+  const size_t shm = (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
+  if (shm_out) *shm_out = shm;
+  if (shm > 160 * 1024) return 0;
+  const int nblocks = B * (Ho / RBW);
+  const int cap = 256 * (int)((160 * 1024) / shm > 4 ? 4 : (160 * 1024) / shm);
+  return nblocks < cap ? nblocks : cap;
 }
 
 static int stem_nsplit(int Wo) {
@@ -305,8 +323,16 @@ int vqa_stem_conv(const float* img, const void* wstem, void* out, float* stats, 
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 
-// bf16 only.  dw [64][7][7][3] fp32 (+=).  Same shape support as vqa_stem_conv.
-int vqa_stem_wgrad(const float* img, const void* dy, float* dw, int B, int H, int W, hipStream_t st) {
+// workgroups of the stem weight-gradient kernels (0: unsupported shape): their deterministic two-pass accumulation needs a scratch
+// of (this many) * 64*147 floats
+int vqa_stem_wgrad_blocks(int B, int H, int W) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  if (Ho % RBW || Wo % 16 || Wo > 256) return 0;
+  return stem_wgrad_grid(B, Ho, Wo, nullptr);
+}
+
+// bf16 only.  dw [64][7][7][3] fp32 (+=).  Same shape support as vqa_stem_conv.  ws: scratch (see vqa_stem_wgrad_blocks) or NULL (atomics)
+int vqa_stem_wgrad(const float* img, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t st) {
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   if (!img || !dy || !dw || Ho % RBW || Wo % 16 || Wo > 256) return VQA_EARG;
   const int nsplit = stem_nsplit(Wo);
@@ -318,14 +344,16 @@ int vqa_stem_wgrad(const float* img, const void* dy, float* dw, int B, int H, in
   int nblocks = B * (Ho / RBW);
   const int cap = 256 * (int)((160 * 1024) / shm > 4 ? 4 : (160 * 1024) / shm);
   int grid = nblocks < cap ? nblocks : cap;
+  float* w = (ws && ws_floats >= (long long)grid * 64 * 147) ? ws : nullptr;
   hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)dy, dw, B, H, W, Ho, Wo,
-                     (const bf16_t*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, nsplit);
-  VQA_LAUNCH_CHECK(); return VQA_OK;
+                     (const bf16_t*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, nsplit, w);
+  VQA_LAUNCH_CHECK();
+  return w ? vqa_slab_reduce(w, dw, grid, 64 * 147, st) : VQA_OK;
 }
 // Fused stem BatchNorm/ReLU/MaxPool backward + weight gradient: dy = A*g + B*y + C is rebuilt on the fly from the raw conv
 // output y [B][Ho][Wo][64], the pooled gradient dpool [B][Hp][Wp][64] + argmax idx, coef (4*64) and bcoef (3*64).
 int vqa_stem_wgrad_fused(const float* img, const void* y, const void* dpool, const uint8_t* idx, const float* coef, const float* bcoef,
-                         float* dw, int B, int H, int W, hipStream_t st) {
+                         float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t st) {
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1, Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
   if (!img || !y || !dpool || !idx || !coef || !bcoef || !dw || Ho % RBW || Wo % 16 || Wo > 256) return VQA_EARG;
   const int nsplit = stem_nsplit(Wo);
@@ -337,9 +365,11 @@ int vqa_stem_wgrad_fused(const float* img, const void* y, const void* dpool, con
   int nblocks = B * (Ho / RBW);
   const int cap = 256 * (int)((160 * 1024) / shm > 4 ? 4 : (160 * 1024) / shm);
   int grid = nblocks < cap ? nblocks : cap;
+  float* w = (ws && ws_floats >= (long long)grid * 64 * 147) ? ws : nullptr;
   hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)y, dw, B, H, W, Ho, Wo,
-                     (const bf16_t*)dpool, idx, coef, bcoef, Hp, Wp, nsplit);
-  VQA_LAUNCH_CHECK(); return VQA_OK;
+                     (const bf16_t*)dpool, idx, coef, bcoef, Hp, Wp, nsplit, w);
+  VQA_LAUNCH_CHECK();
+  return w ? vqa_slab_reduce(w, dw, grid, 64 * 147, st) : VQA_OK;
 }
 
 }  // extern "C"

@@ -751,7 +751,9 @@ class HipEngine:
             dwv = self._gslice(G, "image_encoder.stem.0.weight")
             if K.PROFILE is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
-            call("vqa_stem_wgrad_fused", ptr(st["images"]), ptr(st["y"]), ptr(dxc), ptr(st["idx"]), ptr(st["coef"]), ptr(bc), ptr(dwv), B, IH, IW)
+            ws, wsf = K.stem_wgrad_scratch(dxc.device, B, IH, IW)
+            call("vqa_stem_wgrad_fused", ptr(st["images"]), ptr(st["y"]), ptr(dxc), ptr(st["idx"]), ptr(st["coef"]), ptr(bc), ptr(dwv), B, IH, IW,
+                 ptr(ws), wsf)
             if K.PROFILE is not None:
                 e1.record(); K.PROFILE.append(("stem_wgrad_kernel<true>", 2.0 * B * H1 * W1 * 64 * 147, e0, e1,
                                                             B * 3 * IH * IW * 4 + B * H1 * W1 * 64 * 2 + dxc.numel() * 3))

@@ -94,7 +94,9 @@ def wgrad3x3_c64(x, dy, dw, B, H, W):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("vqa_wgrad3x3_c64", ptr(x), ptr(dy), ptr(dw), B, H, W)
+    wsf = c64_blocks(B, H, W) * 64 * 576                      # one partial dW per persistent workgroup, reduced in a fixed order
+    ws = torch.empty(wsf, device=x.device, dtype=torch.float32)
+    call("vqa_wgrad3x3_c64", ptr(x), ptr(dy), ptr(dw), B, H, W, ptr(ws), wsf)
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("wgrad3x3_c64_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
@@ -121,10 +123,17 @@ def stem_wgrad(img, dy, dw, B, H, W):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("vqa_stem_wgrad", ptr(img), ptr(dy), ptr(dw), B, H, W)
+    ws, wsf = stem_wgrad_scratch(img.device, B, H, W)
+    call("vqa_stem_wgrad", ptr(img), ptr(dy), ptr(dw), B, H, W, ptr(ws), wsf)
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("stem_wgrad_kernel<false>", 2.0 * B * Ho * Wo * 64 * 147, e0, e1, B * 3 * H * W * 4 + B * Ho * Wo * 64 * 2))
+
+
+def stem_wgrad_scratch(device, B, H, W):
+    """Scratch for the deterministic accumulation of the stem weight-gradient kernels: one [64][147] slab per workgroup."""
+    wsf = L.count("vqa_stem_wgrad_blocks", B, H, W) * 64 * 147
+    return torch.empty(wsf, device=device, dtype=torch.float32), wsf
 
 
 def stem_conv_blocks(B, H, W) -> int:
