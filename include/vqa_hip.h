@@ -172,6 +172,17 @@ int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float l
               float weight_decay, float bias_corr1, float bias_corr2, const float* sumsq, float max_norm, float gscale,
               hipStream_t stream);
 
+/* ---- input pipeline on the GPU -----------------------------------------------------------------
+ * vqa_image_normalize: torchvision ToTensor + Normalize of data/preprocess.py:34-35,117-121 -- uint8 HWC [B][H][W][3] ->
+ * float32 NCHW, (u/255 - mean[c]) / std[c] in torch's operation order (bit-identical), optional per-sample horizontal flip
+ * (flip[b] != 0; RandomHorizontalFlip, data/preprocess.py:73).  W % 4 == 0.  Resize / ColorJitter (PIL) stay on the host.
+ * vqa_pack_tokens: Tokenizer.encode (utils/tokenizer.py:196-250) for a batch -- ragged vocabulary indices words[offsets[b] ..
+ * offsets[b+1]) -> ids / mask int64 [B][L]: START + words + END, truncated to L with END forced onto the last slot, PAD after. */
+int vqa_image_normalize(const uint8_t* in_hwc, float* out_nchw, const uint8_t* flip, int B, int H, int W, float mean0, float mean1,
+                        float mean2, float std0, float std1, float std2, hipStream_t stream);
+int vqa_pack_tokens(const int* words, const long long* offsets, long long* ids, long long* mask, int B, int L, int add_special,
+                    int start_idx, int end_idx, int pad_idx, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

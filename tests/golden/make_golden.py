@@ -160,12 +160,55 @@ def gen_metrics():
     print("metrics", per_batch, m["accuracy"], m["accuracy_top5"])
 
 
+QUESTIONS = [
+    "What color is the cat?", "How many people are there?", "Is this a beach?", "What is the man doing?",
+    "What's in the background?", "what   is  the  WOMAN holding -- an umbrella, or a (red) bag?!", "", "?!...",
+    "Is the dog's tail up", "Don't the two giraffes look like they're eating leaves from the very tall tree behind the fence",
+    "one two three four five six seven eight nine ten eleven twelve thirteen fourteen fifteen sixteen seventeen eighteen",
+    "a b c d e f g h i j k l m n o p q r", "a b c d e f g h i j k l m n o p q r s", "a b c d e f g h i j k l m n o p q r s t u v",
+    "Is it snowing_outside at 5pm?", "caf\u00e9 na\u00efve \u00fcber stra\u00dfe", "What\tcolor\nis   the\r\nkite", "zebra xylophone quux",
+]
+
+
+def gen_input():
+    """utils/tokenizer.py Tokenizer (the real reference class) on a fixed question list: vocabulary, ids, masks for two
+    (max_length, add_special_tokens) settings.  Image half: torchvision is absent here, so ToTensor + Normalize are restated
+    with torch only (oracle.input_oracle.to_tensor_normalize) -- the fixture pins the kernel to that restatement, not to torchvision."""
+    import json
+    from utils.tokenizer import Tokenizer  # the reference
+    from oracle import input_oracle as IO
+    out = {}
+    for tag, max_len in (("l20", 20), ("l8", 8)):
+        tok = Tokenizer(max_length=max_len, vocab_size=40)
+        tok.build_vocab(QUESTIONS[:14], min_freq=1)
+        ids, mask = tok.batch_encode(QUESTIONS)
+        ids_ns, mask_ns = tok.batch_encode(QUESTIONS, add_special_tokens=False)
+        out[f"ids_{tag}"] = np.array(ids, dtype=np.int64); out[f"mask_{tag}"] = np.array(mask, dtype=np.int64)
+        out[f"ids_ns_{tag}"] = np.array(ids_ns, dtype=np.int64); out[f"mask_ns_{tag}"] = np.array(mask_ns, dtype=np.int64)
+        out[f"vocab_{tag}"] = np.array(json.dumps(tok.word2idx, ensure_ascii=True))
+        out[f"decoded_{tag}"] = np.array(json.dumps([tok.decode(r) for r in ids], ensure_ascii=True))
+    out["questions"] = np.array(json.dumps(QUESTIONS, ensure_ascii=True))
+    g = torch.Generator().manual_seed(2024)
+    img = torch.randint(0, 256, (3, 16, 24, 3), generator=g, dtype=torch.uint8)
+    img[0, 0, 0] = torch.tensor([0, 255, 128], dtype=torch.uint8)
+    flip = torch.tensor([0, 1, 0], dtype=torch.uint8)
+    out["img_u8"] = img.numpy()
+    out["img_flip"] = flip.numpy()
+    out["img_norm"] = IO.to_tensor_normalize(img).numpy()
+    out["img_norm_flip"] = IO.to_tensor_normalize(img, flip).numpy()
+    np.savez_compressed(os.path.join(OUT, "input_pipeline.npz"), **out)
+    print("input_pipeline", out["ids_l20"].shape, int(out["mask_l20"].sum()), "vocab", len(json.loads(str(out["vocab_l20"]))))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         gen_metrics(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "input":
+        gen_input(); sys.exit(0)
     gen_full_eval()
     gen_full_train("full_train", O.full_config(dropout=0.0, answer_dropout=0.0), seed=2, B=4)
     gen_full_train("small_train", O.full_config(dropout=0.0, answer_dropout=0.0, vocab_size=100, num_answers=10,
                                                 embed_dim=32), seed=3, B=2, image_size=64, seq_len=10, vocab=100)
     gen_overfit()
     gen_metrics()
+    gen_input()

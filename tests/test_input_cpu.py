@@ -1,0 +1,61 @@
+"""CPU: the input-side oracle (oracle/input_oracle.py) and the host half of the drop-in tokenizer against the fixture written
+by the REAL reference `utils.tokenizer.Tokenizer` (tests/golden/input_pipeline.npz, make_golden.py gen_input): ids, masks,
+decode, with and without special tokens, at max_length 20 and 8 (truncation with END forced onto the last slot), including
+empty / punctuation-only questions, apostrophes, underscores, unicode words, tabs and newlines, unknown words."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from _pkg import pkg
+from oracle import input_oracle as IO
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "input_pipeline.npz"))
+
+
+@pytest.mark.parametrize("tag,L", [("l20", 20), ("l8", 8)])
+def test_oracle_encode_matches_reference_tokenizer(gold, tag, L):
+    qs = json.loads(str(gold["questions"]))
+    vocab = json.loads(str(gold[f"vocab_{tag}"]))
+    ids, mask = IO.batch_encode(qs, vocab, L)
+    assert np.array_equal(ids, gold[f"ids_{tag}"]) and np.array_equal(mask, gold[f"mask_{tag}"])
+    ids, mask = IO.batch_encode(qs, vocab, L, add_special_tokens=False)
+    assert np.array_equal(ids, gold[f"ids_ns_{tag}"]) and np.array_equal(mask, gold[f"mask_ns_{tag}"])
+
+
+@pytest.mark.parametrize("tag,L", [("l20", 20), ("l8", 8)])
+def test_dropin_tokenizer_host_half_matches_reference(gold, tag, L, tmp_path):
+    T = pkg().load_dropin_tokenizer()
+    qs = json.loads(str(gold["questions"]))
+    tok = T.Tokenizer(max_length=L, vocab_size=40)
+    tok.build_vocab(qs[:14], min_freq=1)                       # same corpus / limits as the fixture: the vocabulary itself must agree
+    assert tok.word2idx == json.loads(str(gold[f"vocab_{tag}"]))
+    ids, mask = tok.batch_encode(qs)
+    assert np.array_equal(np.array(ids), gold[f"ids_{tag}"]) and np.array_equal(np.array(mask), gold[f"mask_{tag}"])
+    ids, mask = tok.batch_encode(qs, add_special_tokens=False)
+    assert np.array_equal(np.array(ids), gold[f"ids_ns_{tag}"]) and np.array_equal(np.array(mask), gold[f"mask_ns_{tag}"])
+    assert [tok.decode(r) for r in gold[f"ids_{tag}"]] == json.loads(str(gold[f"decoded_{tag}"]))
+    # vocabulary file format round trip (utils/tokenizer.py:274-310)
+    path = str(tmp_path / "vocab.json")
+    tok.save(path)
+    t2 = T.Tokenizer()
+    t2.load(path)
+    assert t2.word2idx == tok.word2idx and t2.max_length == L and t2.encode(qs[5]) == tok.encode(qs[5])
+    # no silent CPU path for the device packer
+    with pytest.raises(RuntimeError):
+        tok.batch_encode_device(qs, device="cpu")
+
+
+def test_image_oracle_matches_fixture_and_formula(gold):
+    import torch
+    img = torch.from_numpy(gold["img_u8"])
+    out = IO.to_tensor_normalize(img)
+    assert np.array_equal(out.numpy(), gold["img_norm"])
+    assert np.array_equal(IO.to_tensor_normalize(img, gold["img_flip"]).numpy(), gold["img_norm_flip"])
+    # spot values: (u/255 - mean) / std
+    assert abs(float(out[0, 0, 0, 0]) - (0.0 - 0.485) / 0.229) < 1e-6
+    assert abs(float(out[0, 1, 0, 0]) - (1.0 - 0.456) / 0.224) < 1e-6

@@ -43,3 +43,26 @@ def load_dropin_metrics():
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def _load_dropin_file(name, *rel):
+    import importlib.util
+    import os
+    import sys
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(dropin_path(), *rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_dropin_tokenizer():
+    """The drop-in `utils.tokenizer` (batch encoding packed on the GPU), without disturbing an imported `utils` package."""
+    return _load_dropin_file("vqa_hip_dropin_utils_tokenizer", "utils", "tokenizer.py")
+
+
+def load_dropin_preprocess():
+    """The drop-in `data.preprocess` (ToTensor + Normalize on the GPU, gpu_collate_fn)."""
+    return _load_dropin_file("vqa_hip_dropin_data_preprocess", "data", "preprocess.py")

@@ -71,6 +71,8 @@ SIGNATURES = {
     "vqa_cross_entropy": [I, P, P, P, P, P, I, I, F, P, P],
     "vqa_convert": [I, I, P, P, LL, P],
     "vqa_sumsq": [P, LL, P, P],
+    "vqa_image_normalize": [P, P, P, I, I, I, F, F, F, F, F, F, P],
+    "vqa_pack_tokens": [P, P, P, P, I, I, I, I, I, I, P],
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P],
 }
 _NO_STATUS = {"vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
