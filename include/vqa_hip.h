@@ -32,7 +32,7 @@ int vqa_igemm_mtiles(int M, int N, int loader);
 int vqa_igemm_variant(int dtype, int loader, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
                       int R, int S, int stride, int pad);
 int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, const float* bias, const void* addend,
-              const void* addmask, float* stats, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
+              const void* addmask, const void* outmask /* out *= (outmask > 0), applied last */, float* stats, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
               hipStream_t stream);
 /* dw[N][Kw] += dy[M][N]^T * gather(x)[M][Kw], split over the M pixels.
@@ -110,7 +110,7 @@ int vqa_se_fwd(int dtype, const void* x, const float* w1, const float* w2, float
                void* out, int B, int HW, int C, int Cr, hipStream_t stream);
 int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, const float* w2, const float* pooled,
                const float* hidden, const float* scale, float* scratch /* B*(2C+Cr) */, void* dx, float* dw1, float* dw2,
-               int B, int HW, int C, int Cr, hipStream_t stream);
+               int B, int HW, int C, int Cr, int mask_out /* dx *= (x > 0): x is a post-ReLU activation */, hipStream_t stream);
 /* ---- SpatialAttention.forward (models/attention_modules.py:223-243) and its backward ----------------------------- */
 int vqa_spatial_fwd(int dtype, const void* x, const float* w /* (1,2,7,7) */, float* pooled2, int* argmax, float* amap,
                     void* out, int B, int H, int W, int C, hipStream_t stream);

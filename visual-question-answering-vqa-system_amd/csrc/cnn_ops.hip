@@ -471,9 +471,13 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
 }
 
 // dx = dout*scale[b][c] + dpool[b][c]/HW   (same thread / index scheme as scale_kernel)
+// xmask != nullptr: dx is additionally multiplied by (xmask > 0).  xmask is the SE input = the post-ReLU output of the stage's
+// last residual block, so the block's backward receives its gradient ALREADY masked by its ReLU and never re-reads that
+// activation (BatchNorm-backward reduce + apply and the identity-path addend: three reads saved for one here).
 template <typename T>
 __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__ dout, const float* __restrict__ scale, const float* __restrict__ dpool,
-                                                           T* __restrict__ dx, unsigned npix, int HW, int C, unsigned long long mul_hw) {
+                                                           T* __restrict__ dx, unsigned npix, int HW, int C, unsigned long long mul_hw,
+                                                           const T* __restrict__ xmask) {
   constexpr int VEC = Vec16<T>::N;
   const float inv = 1.f / (float)HW;
   const int cv = C / VEC, lanes_r = 256 / cv, c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
@@ -482,12 +486,17 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
     const unsigned b = (unsigned)(((unsigned long long)pix * mul_hw) >> 40);
     const f32x4* sp = reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c0);
     const f32x4* dp = reinterpret_cast<const f32x4*>(dpool + (size_t)b * C + c0);
-    Vec16<T> d = ldg16(dout + e), o;
+    Vec16<T> d = ldg16(dout + e), o, xm;
+    if (xmask) xm = ldg16(xmask + e);
 #pragma unroll
     for (int q4 = 0; q4 < VEC / 4; ++q4) {
       const f32x4 s4 = sp[q4], p4 = dp[q4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o.set(q4 * 4 + j, d.get(q4 * 4 + j) * s4[j] + p4[j] * inv);
+      for (int j = 0; j < 4; ++j) {
+        float v = d.get(q4 * 4 + j) * s4[j] + p4[j] * inv;
+        if (xmask && !(xm.get(q4 * 4 + j) > 0.f)) v = 0.f;
+        o.set(q4 * 4 + j, v);
+      }
     }
     stg16(dx + e, o);
   }
@@ -755,7 +764,7 @@ int vqa_se_fwd(int dtype, const void* x, const float* w1, const float* w2, float
 }
 // scratch: dz2[B*C] | dh[B*Cr] | dpool[B*C] floats
 int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, const float* w2, const float* pooled, const float* hidden,
-               const float* scale, float* scratch, void* dx, float* dw1, float* dw2, int B, int HW, int C, int Cr, hipStream_t st) {
+               const float* scale, float* scratch, void* dx, float* dw1, float* dw2, int B, int HW, int C, int Cr, int mask_out, hipStream_t st) {
   const int VEC = dtype ? 8 : 4;
   if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
   float* dz2 = scratch; float* dh = dz2 + (size_t)B * C; float* dpool = dh + (size_t)B * Cr;
@@ -764,8 +773,8 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
      hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr));
   const size_t npix = (size_t)B * HW;
   if (npix >= (1ull << 28)) return VQA_EARG;
-  DT(hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const float*)dout, scale, dpool, (float*)dx, (unsigned)npix, HW, C, magic40(HW)),
-     hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const bf16_t*)dout, scale, dpool, (bf16_t*)dx, (unsigned)npix, HW, C, magic40(HW)));
+  DT(hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const float*)dout, scale, dpool, (float*)dx, (unsigned)npix, HW, C, magic40(HW), mask_out ? (const float*)x : nullptr),
+     hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const bf16_t*)dout, scale, dpool, (bf16_t*)dx, (unsigned)npix, HW, C, magic40(HW), mask_out ? (const bf16_t*)x : nullptr));
   hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 255) / 256, B >= 64 ? 8 : 1), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }

@@ -19,6 +19,7 @@ enum { LOADER_NHWC = 0, LOADER_STEM = 1, LOADER_DGRAD2 = 2 };
 struct IGemmParams {
   const void* a; const void* w; void* out;
   const float* bias; const void* addend; const void* addmask; float* stats;
+  const void* outmask;       // != nullptr: out = (... + addend) * (outmask > 0): the consumer's ReLU mask applied by the producer
   int M, N, Kp, Kw;          // Kp: reduction length rounded up to BK; Kw: weight row length (elements)
   int B, H, W, C;            // source tensor (NHWC; NCHW fp32 image for the stem loader)
   int Ho, Wo;                // spatial dims of the GEMM rows (M = B*Ho*Wo)
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
   T* outT = reinterpret_cast<T*>(p.out);
   const T* addT = reinterpret_cast<const T*>(p.addend);
   const T* mskT = reinterpret_cast<const T*>(p.addmask);
+  const T* omT = reinterpret_cast<const T*>(p.outmask);
   const bool vec_ok = (p.N % VEC) == 0;
   for (int row = tid / VR; row < BM; row += RP) {
     int m = m0 + row;
@@ -583,12 +585,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { const float x = v.get(j); v.set(j, x < 0.f ? 0.f : x); }
       }
+      if (omT) {                                       // data gradient handed to the previous block already masked by ITS ReLU
+        Vec16<T> ov = ldg16(omT + off);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) if (!(ov.get(j) > 0.f)) v.set(j, 0.f);
+      }
       stg16(outT + off, v);
     } else {
       for (int j = 0; j < VEC && n + j < p.N; ++j) {
         float x = v.get(j);
         if (addT) { float a = to_f<T>(addT[off + j]); x += (!mskT || to_f<T>(mskT[off + j]) > 0.f) ? a : 0.f; }
         if (p.relu == 2 && x < 0.f) x = 0.f;
+        if (omT && !(to_f<T>(omT[off + j]) > 0.f)) x = 0.f;
         outT[off + j] = from_f<T>(x);
       }
     }
@@ -1378,7 +1386,7 @@ int vqa_igemm_variant(int dtype, int loader, int M, int N, int Kw, int B, int H,
 }
 
 int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, const float* bias,
-              const void* addend, const void* addmask, float* stats,
+              const void* addend, const void* addmask, const void* outmask, float* stats,
               int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
               hipStream_t st) {
@@ -1394,7 +1402,7 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
   if ((long)M != (long)B * Ho * Wo) return VQA_EARG;
   if (drop_p > 0.f && (unsigned long long)M * (unsigned long long)N >= (1ull << 32)) return VQA_EARG;   // 32-bit dropout counter
   IGemmParams p;
-  p.a = a; p.w = w; p.out = out; p.bias = bias; p.addend = addend; p.addmask = addmask; p.stats = stats;
+  p.a = a; p.w = w; p.out = out; p.bias = bias; p.addend = addend; p.addmask = addmask; p.stats = stats; p.outmask = outmask;
   p.M = M; p.N = N; p.Kw = Kw; p.Kp = (Kw + BK - 1) / BK * BK;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
   p.transposed = transposed; p.relu = relu; p.drop_p = drop_p; p.drop_seed = drop_seed; p.a2 = nullptr;
@@ -1425,7 +1433,7 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
   const int VEC = dtype ? 8 : 4, BK = dtype ? 64 : 32;
   if (!dy || !wt || !out || (Ho & 1) || (Wo & 1) || C % BK || N % VEC || R > 3 || R < 1) return VQA_EARG;
   IGemmParams p;
-  p.a = dy; p.a2 = dyd; p.w = wt; p.out = out; p.bias = nullptr; p.addend = nullptr; p.addmask = nullptr; p.stats = nullptr;
+  p.a = dy; p.a2 = dyd; p.w = wt; p.out = out; p.bias = nullptr; p.addend = nullptr; p.addmask = nullptr; p.stats = nullptr; p.outmask = nullptr;
   p.N = N; p.Kw = R * R * C + (dyd ? C : 0); p.Kp = p.Kw; p.M = B * Ho * Wo;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = R; p.stride = 2; p.pad = pad;
   p.transposed = 1; p.relu = 0; p.drop_p = 0.f; p.drop_seed = 0;

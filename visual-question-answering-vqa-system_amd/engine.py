@@ -678,6 +678,7 @@ class HipEngine:
 
         # ---- CNN stages (reverse)
         dxc = dfeat
+        masked = False           # True: dxc already carries the ReLU mask of the block that consumes it (see _block_bwd)
         for s in (4, 3, 2, 1):
             srec = tape["stages"][s - 1]
             ap = f"image_encoder.stage{s}.attention"
@@ -696,10 +697,18 @@ class HipEngine:
                 dxn = torch.empty_like(r["x"])
                 call("vqa_se_bwd", dt(T), ptr(dxc), ptr(r["x"]), ptr(self.P(ap + ".se.fc1.weight")), ptr(self.P(ap + ".se.fc2.weight")),
                      ptr(r["pooled"]), ptr(r["hidden"]), ptr(r["scale"]), ptr(scratch), ptr(dxn),
-                     ptr(self._gslice(G, ap + ".se.fc1.weight")), ptr(self._gslice(G, ap + ".se.fc2.weight")), B, r["HW"], r["C"], r["Cr"])
+                     ptr(self._gslice(G, ap + ".se.fc1.weight")), ptr(self._gslice(G, ap + ".se.fc2.weight")), B, r["HW"], r["C"], r["Cr"], 1)
                 dxc = dxn
-            for rec in reversed(srec["blocks"]):
-                dxc = self._block_bwd(rec, dxc, G, training)
+                masked = True                 # the SE input IS the last block's post-ReLU output: its mask was applied on the way out
+            else:
+                masked = False
+            nb = len(srec["blocks"])
+            for bi in range(nb - 1, -1, -1):
+                rec = srec["blocks"][bi]
+                # the gradient handed to the previous block of the stage is masked by THAT block's ReLU in this block's epilogue
+                hand_mask = rec["x"] if (bi > 0 and "yd" not in rec) else None
+                dxc = self._block_bwd(rec, dxc, G, training, masked=masked, outmask=hand_mask)
+                masked = hand_mask is not None
             if not self._deferred:                # stage 1: its held-back weight gradients are released below, report it there
                 seg(f"image_encoder.stage{s}")
 
@@ -763,14 +772,17 @@ class HipEngine:
             K.wgrad(dy, st["images"], LY.mat_of(G, self.E["image_encoder.stem.0.weight"]), B * H1 * W1, 64, 147, st["geom"], dtype=T,
                     loader=K.LOADER_STEM)
 
-    def _block_bwd(self, rec, dout, G, training):
-        """ResidualBlock backward (reference forward: models/cnn_backbone.py:164-197)."""
+    def _block_bwd(self, rec, dout, G, training, masked=False, outmask=None):
+        """ResidualBlock backward (reference forward: models/cnn_backbone.py:164-197).
+        masked: `dout` was already multiplied by (out > 0) by its producer, so the block output is never re-read here.
+        outmask: activation whose sign masks the returned gradient (the previous block's post-ReLU output = this block's input)."""
         T = self.dtype
         p, Cout, Cin, M = rec["p"], rec["Cout"], rec["Cin"], rec["M"]
         has_ds = "yd" in rec
         last = p == "image_encoder.stage1.blocks.0"           # its weight gradients are released with the stem backward (deferring all of stage 1 measured worse)
         gs = lambda n: self._gslice(G, n)
-        dy2, dyd = K.bn_bwd(dout, rec["out"], rec["y2"], rec["c2"], self.P(p + ".bn2.weight"), Cout, training,
+        out_act = None if masked else rec["out"]
+        dy2, dyd = K.bn_bwd(dout, out_act, rec["y2"], rec["c2"], self.P(p + ".bn2.weight"), Cout, training,
                             gs(p + ".bn2.weight"), gs(p + ".bn2.bias"),
                             y2=rec.get("yd"), coef2=rec.get("cd"),
                             gamma2=self.P(p + ".downsample.1.weight") if has_ds else None,
@@ -809,9 +821,9 @@ class HipEngine:
                 geom_dd = (B, Ho, Wo, Cout, H, W, 1, 1, stride, 0)
                 dxd, _, _ = K.igemm(dyd, self.Wt(p + ".downsample.0.weight"), Md, Cin, Cout, geom_dd, dtype=T, transposed=1)
                 dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1, addend=dxd)
-        elif c64_1:
+        elif c64_1 and not masked and outmask is None:
             dx, _, _ = K.conv3x3_c64(dy1, self._wflip(p + ".conv1.weight"), B, H, W, addend=dout, addmask=rec["out"])
         else:
             dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
-                               addend=dout, addmask=rec["out"])
+                               addend=dout, addmask=out_act, outmask=outmask)
         return dx

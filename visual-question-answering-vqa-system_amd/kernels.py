@@ -156,7 +156,7 @@ def stem_conv(img, wstem, B, H, W, want_stats):
     return y, stats, nb
 
 
-def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=None, addmask=None, want_stats=False,
+def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=None, addmask=None, outmask=None, want_stats=False,
           transposed=0, relu=0, drop_p=0.0, drop_seed=0, out=None):
     """out[M][N] = gather(a) @ w[N][Kw]^T with the fused epilogue.  geom = (B, H, W, C, Ho, Wo, R, S, stride, pad).
     Returns (out, stats_slab | None, mtiles)."""
@@ -170,7 +170,7 @@ def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("vqa_igemm", dt(dtype), loader, ptr(a), ptr(w), ptr(out), ptr(bias), ptr(addend), ptr(addmask), ptr(stats),
+    call("vqa_igemm", dt(dtype), loader, ptr(a), ptr(w), ptr(out), ptr(bias), ptr(addend), ptr(addmask), ptr(outmask), ptr(stats),
          M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad, transposed, relu, float(drop_p), int(drop_seed))
     if PROFILE is not None:
         e1.record()
