@@ -119,17 +119,10 @@ def test_train_step_fp32_matches_reference_golden(golden_dir, tag, cfgkw, seed, 
 
 
 def test_train_bf16_grads_close_to_oracle():
-    """bf16 path, B=8, dropout 0: loss and EVERY parameter tensor's gradient against the fp32 CPU oracle.
-
-    What bf16 itself costs is measured, not guessed: the same oracle under PyTorch's CPU bf16 autocast gives per-tensor
-    relative errors e = |g - g_fp32| / |g_fp32| of 0.4-0.55 for the CNN weights at this batch size (cosine 0.85-0.93; gradients
-    at random init are sums with heavy cancellation, and train-mode BN at B=8 amplifies 8-bit rounding), while the HIP fp32
-    path sits at cosine 1.0000 on every tensor (tools/diag_bf16_grads.py).  So the bound is self-calibrating:
-        every tensor:  e_hip_bf16 <= 1.25 * e_cpu_autocast_bf16 + 0.10        (not noisier than torch's own bf16, + margin)
-        and in any case e_hip_bf16 <= 0.75 for weights with >= 2 dims          (a wrong tile / halo mask / permutation gives e >= 1)
-    except the squeeze-excitation fc1 weights of stages 1-3 (|g| ~ 1e-2, a 4..16 x C matrix fed by a global average: both bf16
-    implementations decorrelate there, the autocast run even flips sign at B=8): norm within a factor 2.5 only.
-    The worst tensor is named in the assertion message."""
+    """bf16 path, B=8, dropout 0: loss within 2e-2 and EVERY parameter tensor's gradient against the fp32 CPU oracle, held to the
+    measured noise floor of the same model under PyTorch's CPU bf16 autocast (bounds and rationale: tests/_bf16check.py; the worst
+    tensor is named in the assertion message)."""
+    from _bf16check import check_bf16_grads
     cfg = O.full_config(dropout=0.0, answer_dropout=0.0)
     sd = O.init_state_dict(cfg, 7, jitter=True)
     m = _model(cfg, sd, "bf16").train()
@@ -137,40 +130,9 @@ def test_train_bf16_grads_close_to_oracle():
     logits, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
     loss = torch.nn.functional.cross_entropy(logits, answers.to(DEV))
     loss.backward()
-    names = O.parameter_names(cfg)
-
-    def oracle(autocast):
-        tr = O.OracleTrainer(sd, cfg)
-        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
-            lo, _ = O.vqa_forward(images, ids, mask, tr.sd, cfg, True, {})
-            l = torch.nn.functional.cross_entropy(lo.float(), answers)
-        l.backward()
-        return {n: tr.sd[n].grad.float().reshape(-1) for n in names}, float(l)
-
-    ref, lref = oracle(False)
-    acb, _ = oracle(True)
-    assert abs(loss.item() - lref) < 2e-2
-    P = dict(m.named_parameters())
     noisy = {f"image_encoder.stage{s}.attention.se.fc1.weight" for s in (1, 2, 3)}
-    rows = []
-    for n in names:
-        g, r, a = P[n].grad.detach().float().cpu().reshape(-1), ref[n], acb[n]
-        rn = float(r.norm())
-        if rn < 1e-10:
-            assert float(g.norm()) < 1e-6, n
-            continue
-        rows.append((n, float((g - r).norm()) / rn, float((a - r).norm()) / rn, float(g.norm()) / rn, P[n].dim()))
-    worst = max((t for t in rows if t[0] not in noisy), key=lambda t: t[1] - 1.25 * t[2])
-    for n, e_hip, e_acb, ratio, dim in rows:
-        if n in noisy:
-            assert 0.4 < ratio < 2.5, (n, ratio)
-            continue
-        assert e_hip <= 1.25 * e_acb + 0.10, (n, e_hip, e_acb, "worst", worst)
-        if dim >= 2:
-            assert e_hip <= 0.75, (n, e_hip, "worst", worst)
-    # whole-model gradient vector
-    G, R, A = (torch.cat([d[n] for n in names]) for d in ({n: P[n].grad.detach().float().cpu().reshape(-1) for n in names}, ref, acb))
-    assert float((G - R).norm() / R.norm()) <= 1.15 * float((A - R).norm() / R.norm()) + 0.02
+    worst, lref = check_bf16_grads(m, sd, cfg, images, ids, mask, answers, noisy)
+    assert abs(loss.item() - lref) < 2e-2
 
 
 def test_train_dropout_runs_and_is_deterministic_per_seed():

@@ -96,3 +96,26 @@ def test_stress_shape_384px_144_tokens_matches_oracle():
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             m49(images.to(DEV), ids.to(DEV), mask.to(DEV))
+
+
+def test_stress_shape_bf16_train_step_matches_oracle():
+    """BASELINE configs[4] at B=2 in the THROUGHPUT dtype: 384x384 -> 144 image tokens, d=512 (head dim 64), 8 text layers,
+    2000 answers, bf16 train step with dropout 0 against the fp32 CPU oracle -- loss, and every tensor's gradient held to the
+    bf16 noise floor of the same model (tests/_bf16check.py).  Oracle parity only ("parity unpinned" vs the reference, which
+    cannot run this shape).  Cross-attention has 144 keys."""
+    from _bf16check import check_bf16_grads
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0, vocab_size=500, num_answers=2000, embed_dim=512, num_transformer_layers=8,
+                        num_image_tokens=144)
+    sd = O.init_state_dict(cfg, 79, jitter=True)
+    B = 2
+    images, ids, mask, answers = O.synthetic_batch(B, seed=80, image_size=384, seq_len=20, vocab=500, num_answers=2000)
+    m = pkg().load_dropin().VQAModel(**cfg, compute_dtype="bf16")
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    logits, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits, answers.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    noisy = {f"image_encoder.stage{s}.attention.se.fc1.weight" for s in (1, 2, 3)}
+    worst, lref = check_bf16_grads(m, sd, cfg, images, ids, mask, answers, noisy)
+    assert abs(loss.item() - lref) < 3e-2
