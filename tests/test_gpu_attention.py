@@ -11,7 +11,10 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("case", [(3, 8, 20, 20, 32, True, 0.0), (2, 8, 20, 49, 32, False, 0.0), (2, 4, 17, 64, 64, True, 0.0),
-                                  (5, 8, 20, 49, 32, False, 0.1), (1, 2, 32, 33, 32, True, 0.25)])
+                                  (5, 8, 20, 49, 32, False, 0.1), (1, 2, 32, 33, 32, True, 0.25),
+                                  # five key tiles: the 144 image tokens of the 384x384 stress shape (d=512 -> head dim 64), tails, masks
+                                  (3, 8, 20, 144, 64, False, 0.0), (2, 8, 20, 144, 64, False, 0.1), (2, 4, 32, 160, 32, True, 0.0),
+                                  (3, 2, 7, 65, 32, True, 0.2), (1, 8, 20, 129, 64, True, 0.0)])
 def test_mfma_attention_forward(case):
     L = sub("_lib")
     B, H, Lq, Lk, hd, masked, p = case
@@ -66,7 +69,9 @@ def test_mfma_attention_all_masked_row_is_nan():
 
 
 @pytest.mark.parametrize("case", [(3, 8, 20, 20, 32, True, 0.0), (2, 8, 20, 49, 32, False, 0.0), (2, 4, 17, 64, 64, True, 0.0),
-                                  (5, 8, 20, 49, 32, False, 0.1), (1, 2, 32, 33, 32, True, 0.25), (2, 2, 20, 20, 64, False, 0.1)])
+                                  (5, 8, 20, 49, 32, False, 0.1), (1, 2, 32, 33, 32, True, 0.25), (2, 2, 20, 20, 64, False, 0.1),
+                                  (3, 8, 20, 144, 64, False, 0.0), (2, 8, 20, 144, 64, False, 0.1), (2, 4, 32, 160, 32, True, 0.0),
+                                  (3, 2, 7, 65, 32, True, 0.2), (1, 8, 20, 129, 64, True, 0.0)])
 def test_mfma_attention_backward(case):
     """bf16 MFMA attention backward vs the LDS/VALU kernel (same inputs, same saved probabilities, same dropout mask) and,
     without dropout, vs torch autograd of the fp32 formula."""

@@ -167,7 +167,7 @@ def _attn_ref(q, k, v, kmask, keep, p, heads):
     return ctx.transpose(1, 2).reshape(B, Lq, d), pr
 
 
-@pytest.mark.parametrize("kind,Lk", [("mfma", 20), ("mfma", 49), ("valu", 20), ("valu", 49)])
+@pytest.mark.parametrize("kind,Lk", [("mfma", 20), ("mfma", 49), ("mfma", 144), ("valu", 20), ("valu", 49)])
 def test_attention_dropout_forward_and_backward_share_the_mask(kind, Lk):
     """Attention-probability dropout (text_encoder.py:247-248, cross_attention.py:184-185) in the MFMA (bf16) and VALU (fp32)
     kernels: forward context and dQ/dK/dV equal the torch formula evaluated with the generator's mask (idx = ((b*H+h)*Lq+r)*Lk+c)."""

@@ -618,33 +618,36 @@ int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float l
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+// NKT = key tiles of 32 (2: Lk <= 64, the 49 image tokens / 20 text tokens; 5: Lk <= 160, the 144 image tokens of the 384x384
+// stress shape), WPB = waves (= (batch, head) problems) per workgroup: the wave-private LDS tiles of NKT = 5 fit two per CU.
+template <int HD, int NKT, int WPB>
+__global__ __launch_bounds__(WPB * 64, 1) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                             int ldq, int ldk, int ldv, const float* __restrict__ kmask, float* __restrict__ probs,
                                                             bf16_t* __restrict__ ctx, int ldc, int BH, int H, int Lq, int Lk, float p, uint64_t seed) {
   constexpr int LDV = HD;                       // V tile row stride (elements): 64 / 128 bytes, 8-byte aligned for the transposed reads
-  constexpr int LDP = 65;                       // probability staging row stride (floats)
+  constexpr int KR = NKT * 32;                  // key rows of the tiles
+  constexpr int LDP = KR + 1;                   // probability staging row stride (floats)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.x * 4 + wave;
-  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + wave * (64 * LDV);
-  float* Ps = reinterpret_cast<float*>(smem + 4 * 64 * LDV * 2) + wave * (32 * LDP);
+  const int bh = blockIdx.x * WPB + wave;
+  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + wave * (KR * LDV);
+  float* Ps = reinterpret_cast<float*>(smem + WPB * KR * LDV * 2) + wave * (32 * LDP);
   if (bh >= BH) return;                         // whole wave exits together; no block-level barrier is used below
   const int b = bh / H, h = bh - b * H;
   const int r = lane & 31, hh = lane >> 5;
   const float inv_scale = 1.0f / sqrtf((float)HD);
 
   // ---- V -> LDS (rows >= Lk zero), 16-byte vectors
-  for (int i = lane; i < 64 * (HD / 8); i += 64) {
+  for (int i = lane; i < KR * (HD / 8); i += 64) {
     const int row = i / (HD / 8), cv = i - row * (HD / 8);
     u32x4 val = {0u, 0u, 0u, 0u};
     if (row < Lk) val = *reinterpret_cast<const u32x4*>(v + (size_t)(b * Lk + row) * ldv + h * HD + cv * 8);
     *reinterpret_cast<u32x4*>(&Vs[row * LDV + cv * 8]) = val;
   }
   // ---- S^T = K Q^T
-  f32x16 st[2];
+  f32x16 st[NKT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
 #pragma unroll
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
     bf16x8 qf = {};
     if (r < Lq) qf = *reinterpret_cast<const bf16x8*>(q + (size_t)(b * Lq + r) * ldq + h * HD + ks * 16 + 8 * hh);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NKT; ++t) {
       bf16x8 kf = {};
       if (32 * t + r < Lk) kf = *reinterpret_cast<const bf16x8*>(k + (size_t)(b * Lk + 32 * t + r) * ldk + h * HD + ks * 16 + 8 * hh);
       st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, st[t], 0, 0, 0);
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
   // ---- scale, mask, softmax over keys (query = lane&31; keys: (e&3) + 8*(e>>2) + 4*hh + 32*t)
   float m = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
@@ -673,14 +676,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) { const float ex = expf(st[t][e] - m); st[t][e] = ex; sum += ex; }   // all -inf row -> NaN like torch
   sum += __shfl_xor(sum, 32, 64);
   const float rs = 1.0f / sum;
   const size_t prow = ((size_t)bh * Lq + r) * Lk;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
   const int g2 = (lane >> 4) & 1, li = lane & 15, qd = li >> 2, pp = li & 3;
   typedef __attribute__((ext_vector_type(8))) short i16x8;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af;
@@ -727,17 +730,21 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
 
 extern "C" int vqa_attention_fwd_mfma(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const float* kmask, float* probs,
                                       void* ctx, int ldc, int B, int H, int Lq, int Lk, int hd, float p, unsigned long long seed, hipStream_t st) {
-  if (!q || !k || !v || !probs || !ctx || Lq > 32 || Lk > 64 || (hd != 32 && hd != 64) || (ldq % 8) || (ldk % 8) || (ldv % 8)) return VQA_EARG;
+  if (!q || !k || !v || !probs || !ctx || Lq > 32 || Lk > 160 || (hd != 32 && hd != 64) || (ldq % 8) || (ldk % 8) || (ldv % 8)) return VQA_EARG;
   const int BH = B * H;
-  const size_t shm = (size_t)4 * 64 * hd * 2 + (size_t)4 * 32 * 65 * 4;
-  dim3 grid((BH + 3) / 4);
-  if (hd == 32) hipLaunchKernelGGL(attn_fwd_mfma_kernel<32>, grid, dim3(256), shm, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, kmask, probs, (bf16_t*)ctx, ldc, BH, H, Lq, Lk, p, seed);
-  else hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, grid, dim3(256), shm, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, kmask, probs, (bf16_t*)ctx, ldc, BH, H, Lq, Lk, p, seed);
+  auto go = [&](auto kern, int nkt, int wpb) {
+    const size_t shm = (size_t)wpb * (nkt * 32) * hd * 2 + (size_t)wpb * 32 * (nkt * 32 + 1) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(kern, dim3((BH + wpb - 1) / wpb), dim3(wpb * 64), shm, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
+                       kmask, probs, (bf16_t*)ctx, ldc, BH, H, Lq, Lk, p, seed);
+  };
+  if (Lk <= 64) { if (hd == 32) go(&attn_fwd_mfma_kernel<32, 2, 4>, 2, 4); else go(&attn_fwd_mfma_kernel<64, 2, 4>, 2, 4); }
+  else { if (hd == 32) go(&attn_fwd_mfma_kernel<32, 5, 2>, 5, 2); else go(&attn_fwd_mfma_kernel<64, 5, 2>, 5, 2); }
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// bf16 MFMA attention backward: one wave per (batch, head), Lq <= 32, Lk <= 64, head dim HD in {32, 64}.
+// bf16 MFMA attention backward: one wave per (batch, head), Lq <= 32, Lk <= 32*NKT (NKT = 2 or 5), head dim HD in {32, 64}.
 // dP is formed TWICE from the same global 16-byte fragments (MFMAs are free at this size):
 //   orientation 1  dP^T = V . dctx^T   (lane = query, registers = keys)   -> row sums t[q], dS -> dQ = dS . K
 //   orientation 2  dP   = dctx . V^T   (lane = key,   registers = queries) -> dS, dropped P  -> dK = dS^T . Q, dV = Pd^T . dctx
@@ -755,21 +762,22 @@ __device__ __forceinline__ bf16x8 attn_ldsB(const bf16_t* tile, int row0, int c,
   return __builtin_bit_cast(bf16x8, tt);
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ dctx, int ldc, const bf16_t* __restrict__ q,
+template <int HD, int NKT, int WPB>
+__global__ __launch_bounds__(WPB * 64, 1) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ dctx, int ldc, const bf16_t* __restrict__ q,
                                                             const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
                                                             const float* __restrict__ probs, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
                                                             bf16_t* __restrict__ dv, int lddq, int lddk, int lddv, int BH, int H, int Lq, int Lk,
                                                             float p, uint64_t seed) {
-  constexpr int LDP = 65;
-  constexpr int WAVE_BYTES = (64 + 32 + 32) * HD * 2 + 32 * LDP * 4 + 32 * 4;
+  constexpr int KR = NKT * 32;
+  constexpr int LDP = KR + 1;
+  constexpr int WAVE_BYTES = (KR + 32 + 32) * HD * 2 + 32 * LDP * 4 + 32 * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.x * 4 + wave;
+  const int bh = blockIdx.x * WPB + wave;
   if (bh >= BH) return;                         // whole wave exits together; only wave-private LDS, no block barrier below
   char* base = smem + (size_t)wave * WAVE_BYTES;
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(base);            // [64][HD]
-  bf16_t* Qs = Ks + 64 * HD;                               // [32][HD]
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(base);            // [KR][HD]
+  bf16_t* Qs = Ks + KR * HD;                               // [32][HD]
   bf16_t* Os = Qs + 32 * HD;                               // [32][HD]  (dctx)
   float* Ps = reinterpret_cast<float*>(Os + 32 * HD);      // [32][LDP]
   float* Ts = Ps + 32 * LDP;                               // [32]
@@ -780,7 +788,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
   const float keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
 
   // ---- K, Q, dctx -> LDS (16-byte vectors, padding rows zero); probabilities -> LDS
-  for (int i = lane; i < 64 * (HD / 8); i += 64) {
+  for (int i = lane; i < KR * (HD / 8); i += 64) {
     const int row = i / (HD / 8), cv = i - row * (HD / 8);
     u32x4 val = {0u, 0u, 0u, 0u};
     if (row < Lk) val = *reinterpret_cast<const u32x4*>(k + (size_t)(b * Lk + row) * ldk + h * HD + cv * 8);
@@ -799,9 +807,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
   for (int i = lane; i < Lq * Lk; i += 64) { const int qi = i / Lk, kj = i - qi * Lk; Ps[qi * LDP + kj] = probs[(size_t)bh * Lq * Lk + i]; }
 
   // ---- both orientations of dP = dctx V^T from the same global fragments
-  f32x16 d1[2], d2[2];
+  f32x16 d1[NKT], d2[NKT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) { d1[t][e] = 0.f; d2[t][e] = 0.f; }
 #pragma unroll
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
     bf16x8 of = {};
     if (r < Lq) of = *reinterpret_cast<const bf16x8*>(dctx + (size_t)(b * Lq + r) * ldc + h * HD + ks * 16 + 8 * hh);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NKT; ++t) {
       bf16x8 vf = {};
       if (32 * t + r < Lk) vf = *reinterpret_cast<const bf16x8*>(v + (size_t)(b * Lk + 32 * t + r) * ldv + h * HD + ks * 16 + 8 * hh);
       d1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, of, d1[t], 0, 0, 0);      // rows = keys, cols = queries
@@ -822,7 +830,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
   const size_t prow = ((size_t)bh * Lq + r) * Lk;
   float tq = 0.f;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
@@ -837,7 +845,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
   tq += __shfl_xor(tq, 32, 64);
   if (hh == 0) Ts[r] = tq;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
@@ -852,7 +860,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
 #pragma unroll
     for (int e = 0; e < 16; ++e) oq[c][e] = 0.f;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       bf16x8 af;
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
 
   // ---- orientation 2: key = 32t + r, queries = (e&3) + 8(e>>2) + 4hh ; dK = dS^T Q, dV = Pd^T dctx
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < NKT; ++t) {
     const int key = 32 * t + r;
     f32x16 ds2, pd2;
 #pragma unroll
@@ -919,22 +927,17 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
 extern "C" int vqa_attention_bwd_mfma(const void* dctx, int ldc, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
                                       const float* probs, void* dq, void* dk, void* dv, int lddq, int lddk, int lddv,
                                       int B, int H, int Lq, int Lk, int hd, float p, unsigned long long seed, hipStream_t st) {
-  if (!dctx || !q || !k || !v || !probs || !dq || !dk || !dv || Lq > 32 || Lk > 64 || (hd != 32 && hd != 64) ||
+  if (!dctx || !q || !k || !v || !probs || !dq || !dk || !dv || Lq > 32 || Lk > 160 || (hd != 32 && hd != 64) ||
       (ldq % 8) || (ldk % 8) || (ldv % 8) || (ldc % 8)) return VQA_EARG;
   const int BH = B * H;
-  const size_t shm = (size_t)4 * ((64 + 32 + 32) * hd * 2 + 32 * 65 * 4 + 32 * 4);
-  dim3 grid((BH + 3) / 4);
-  if (hd == 32) {
-    static bool attr32 = false;
-    if (!attr32) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr32 = true; }
-    hipLaunchKernelGGL(attn_bwd_mfma_kernel<32>, grid, dim3(256), shm, st, (const bf16_t*)dctx, ldc, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       ldq, ldk, ldv, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, BH, H, Lq, Lk, p, seed);
-  } else {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = true; }
-    hipLaunchKernelGGL(attn_bwd_mfma_kernel<64>, grid, dim3(256), shm, st, (const bf16_t*)dctx, ldc, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       ldq, ldk, ldv, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, BH, H, Lq, Lk, p, seed);
-  }
+  auto go = [&](auto kern, int nkt, int wpb) {
+    const size_t shm = (size_t)wpb * ((nkt * 32 + 32 + 32) * hd * 2 + 32 * (nkt * 32 + 1) * 4 + 32 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(kern, dim3((BH + wpb - 1) / wpb), dim3(wpb * 64), shm, st, (const bf16_t*)dctx, ldc, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, ldq, ldk, ldv, probs, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, BH, H, Lq, Lk, p, seed);
+  };
+  if (Lk <= 64) { if (hd == 32) go(&attn_bwd_mfma_kernel<32, 2, 4>, 2, 4); else go(&attn_bwd_mfma_kernel<64, 2, 4>, 2, 4); }
+  else { if (hd == 32) go(&attn_bwd_mfma_kernel<32, 5, 2>, 5, 2); else go(&attn_bwd_mfma_kernel<64, 5, 2>, 5, 2); }
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 

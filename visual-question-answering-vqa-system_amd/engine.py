@@ -530,7 +530,7 @@ class HipEngine:
         probs = torch.empty((B, heads, Lq, Lk), device=Q.device, dtype=torch.float32)
         ctx = torch.empty((B * Lq, d), device=Q.device, dtype=T)
         sa = self._seed()
-        if T == torch.bfloat16 and Lq <= 32 and Lk <= 64 and hd in (32, 64):
+        if T == torch.bfloat16 and Lq <= 32 and Lk <= 160 and hd in (32, 64):
             call("vqa_attention_fwd_mfma", ptr(Q), ptr(Kt), ptr(V), ldq, ldkv, ldkv, ptr(kmask), ptr(probs), ptr(ctx), d, B, heads, Lq, Lk, hd,
                  float(p), sa)
         else:
@@ -572,7 +572,7 @@ class HipEngine:
             dK, dV = dkv, dkv[:, d:]
         else:
             dQ = torch.empty((B * Lq, d), device=dev, dtype=T); dK = torch.empty((B * Lk, d), device=dev, dtype=T); dV = torch.empty((B * Lk, d), device=dev, dtype=T)
-        if T == torch.bfloat16 and Lq <= 32 and Lk <= 64 and hd in (32, 64):
+        if T == torch.bfloat16 and Lq <= 32 and Lk <= 160 and hd in (32, 64):
             call("vqa_attention_bwd_mfma", ptr(dctx), d, ptr(rec["Q"]), ptr(rec["K"]), ptr(rec["V"]), ldq, ldkv, ldkv, ptr(rec["probs"]),
                  ptr(dQ), ptr(dK), ptr(dV), ldq, ldkv, ldkv, B, heads, Lq, Lk, hd, float(p), rec["sa"])
         else:
