@@ -167,3 +167,46 @@ def test_weight_gradients_are_bit_reproducible():
     K.wgrad(dy, x, b, M, N, Kin, K.linear_geom(M, Kin), dtype=BF)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [(16, 64, 56, True, False), (64, 128, 28, False, True), (4, 128, 12, False, False), (3, 64, 10, True, False)])
+@pytest.mark.parametrize("dtype", [BF, torch.float32])
+def test_data_gradient_epilogue_reduces_batchnorm_backward_sums(case, dtype):
+    """igemm(transposed, bnred=...): the data-gradient launch also emits the BatchNorm-backward column sums of the gradient it
+    stores -- sum g, sum g*xhat(y) [, sum g*xhat(y2)] with g = stored value (* [y*scale+shift > 0] in self-mask mode), after the
+    identity addend and the hand-over mask -- per M tile, in the slab layout vqa_bn_bwd_finalize reads.  Checked against torch on
+    the values the kernel actually stored (so only fp32 summation order differs), at the benchmark tiles (window loader, 128x64 and
+    128x128) and at the 64x64 fallback."""
+    K = sub("kernels")
+    B, C, H, self_mask, dual = case
+    if dtype == torch.float32 and B * H * H > 20000:
+        pytest.skip("fp32 path: small shapes only (exact-fp32 MFMA is 16x slower)")
+    g = torch.Generator().manual_seed(C + H + int(self_mask))
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dtype)
+    M, Kw = B * H * H, 9 * C
+    dy, y, y2, add, om = rnd(M, C), rnd(M, C), rnd(M, C), rnd(M, C), rnd(M, C)
+    w = (torch.randn(C, 9, C, generator=g) * (2.0 / Kw) ** 0.5)
+    coef = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.2,
+                        torch.rand(C, generator=g) + 0.5])                      # scale | shift | mean | invstd
+    coef2 = torch.stack([torch.ones(C), torch.zeros(C), torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5])
+    geom = (B, H, H, C, H, H, 3, 3, 1, 1)
+    wt = K.pack_transpose(w.to(DEV), dtype)
+    bnred = (y.to(DEV), coef.to(DEV), self_mask) + ((y2.to(DEV), coef2.to(DEV)) if dual else ())
+    kw = {} if self_mask else dict(addend=add.to(DEV), outmask=om.to(DEV))
+    dx, slab, mt = K.igemm(dy.to(DEV), wt, M, C, Kw, geom, dtype=dtype, transposed=1, bnred=bnred, **kw)
+    plain, _, _ = K.igemm(dy.to(DEV), wt, M, C, Kw, geom, dtype=dtype, transposed=1, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, plain)                                           # the fused reduction does not change the stored gradient
+    assert slab.shape == (mt, 3, C)
+    gq = dx.float().cpu()
+    yf = y.float()
+    if self_mask:
+        gq = gq * ((yf * coef[0] + coef[1]) > 0)
+    ref0 = gq.sum(0)
+    ref1 = (gq * (yf - coef[2]) * coef[3]).sum(0)
+    s = slab.sum(0).cpu()
+    tol = lambda r: 2e-3 * float(r.abs().max()) + 1e-3
+    assert (s[0] - ref0).abs().max().item() < tol(ref0) and (s[1] - ref1).abs().max().item() < tol(ref1)
+    if dual:
+        ref2 = (gq * (y2.float() - coef2[2]) * coef2[3]).sum(0)
+        assert (s[2] - ref2).abs().max().item() < tol(ref2)

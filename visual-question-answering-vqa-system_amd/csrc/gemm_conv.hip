@@ -20,6 +20,11 @@ struct IGemmParams {
   const void* a; const void* w; void* out;
   const float* bias; const void* addend; const void* addmask; float* stats;
   const void* outmask;       // != nullptr: out = (... + addend) * (outmask > 0): the consumer's ReLU mask applied by the producer
+  // BatchNorm-backward reduction fused into a data-gradient epilogue (bn_slab != nullptr): the tile's final values ARE the
+  // gradient g (bn_self: times [bn_y*scale + shift > 0], the ReLU recomputed from the conv output) entering the BatchNorm whose
+  // conv output is bn_y; per M tile the column sums  sum g | sum g*xhat(bn_y) | sum g*xhat(bn_y2)  go to bn_slab[tile][3][N]
+  // (the layout vqa_bn_bwd_finalize reads), so the standalone reduce pass over g and y is not run.
+  const void* bn_y; const float* bn_coef; const void* bn_y2; const float* bn_coef2; float* bn_slab; int bn_self;
   int M, N, Kp, Kw;          // Kp: reduction length rounded up to BK; Kw: weight row length (elements)
   int B, H, W, C;            // source tensor (NHWC; NCHW fp32 image for the stem loader)
   int Ho, Wo;                // spatial dims of the GEMM rows (M = B*Ho*Wo)
@@ -99,7 +104,7 @@ template <typename T, int BM, int BN, int BK = GT<T>::BK, int ST = 2, int WIN = 
   static constexpr int LD = BK;
   static constexpr int TILES = ST * (BM + 8 * WIN + BN) * LD * (int)sizeof(T);   // WIN: the A buffers hold a window of BM + 8 pixels
   static constexpr int CST = BM * (BN + GT<T>::VEC) * (int)sizeof(T);
-  static constexpr int SMEM = (TILES > CST + 4096 ? TILES : CST + 4096);   // BN-statistics scratch sits right after the C staging area
+  static constexpr int SMEM = (TILES > CST + 8192 ? TILES : CST + 8192);   // BN-statistics / BN-backward scratch sits right after the C staging area
 };
 
 // sum over the 16 lanes of a DPP row (all 16 lanes receive it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
@@ -111,7 +116,9 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2, int WIN = 0>
+// BNRED: the epilogue also reduces BatchNorm-backward column sums (data-gradient launches); a separate instantiation so that the
+// forward / plain kernels keep the lean epilogue (its register arrays cost the 128x64 shape its third workgroup per CU).
+template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2, int WIN = 0, bool BNRED = false>
 __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   // OCC waves per SIMD (2 -> <= 256 VGPRs)
   using G = GT<T>;
   constexpr int VEC = G::VEC, LD = BK;
@@ -472,6 +479,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
 
   }
 
+  // BNRED: the BatchNorm operand rows this thread will need in the store loop are requested NOW, so their latency hides under the
+  // accumulator conversion / LDS staging below instead of serialising the store loop (the loop then issues no loads at all in the
+  // common self-mask case: conv2's data gradient).
+  constexpr int VR_ = BN / VEC, RP_ = NTHR / VR_, NR_ = BM / RP_;
+  Vec16<T> ypre[BNRED ? NR_ : 1];
+  if constexpr (BNRED) {
+    const T* byT = reinterpret_cast<const T*>(p.bn_y);
+    const int nn = n0 + (tid % VR_) * VEC;
+#pragma unroll
+    for (int i = 0; i < NR_; ++i) {
+      const int m = m0 + tid / VR_ + i * RP_;
+      ypre[i] = (m < row_limit && nn < p.N && (p.N % VEC) == 0) ? ldg16(byT + (size_t)m * p.N + nn) : zero16<T>();
+    }
+  }
+
   // ---- epilogue.  The MFMA operands were swapped, so a lane holds 4 CONSECUTIVE COLUMNS of one row:
   //        acc[i][j][r] = C[m = wm*TM + i*16 + (lane & 15)][n = wn*64 + j*16 + (lane >> 4)*4 + r]
   //      -> packed conversion and one 8-byte (bf16) / 16-byte (fp32) LDS store per (i, j) instead of four scalar ones.
@@ -559,45 +581,123 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
   const T* mskT = reinterpret_cast<const T*>(p.addmask);
   const T* omT = reinterpret_cast<const T*>(p.outmask);
   const bool vec_ok = (p.N % VEC) == 0;
-  for (int row = tid / VR; row < BM; row += RP) {
-    int m = m0 + row;
-    const int n = n0 + (tid % VR) * VEC;
-    if (m >= row_limit || n >= p.N) continue;
-    if (LOADER == LOADER_DGRAD2) {
-      const int b = fast_div(m, p.mul_howo), rem = m - b * Hh * Wh, hh = fast_div(rem, p.mul_wo), ww = rem - hh * Wh;
-      m = (b * p.Ho + 2 * hh + (cls >> 1)) * p.Wo + 2 * ww + (cls & 1);
+  // fused BatchNorm-backward reduction: this thread's VEC columns are the same for all its rows
+  const T* bnyT = reinterpret_cast<const T*>(p.bn_y);
+  const T* bny2T = reinterpret_cast<const T*>(p.bn_y2);
+  constexpr bool bnred = BNRED;
+  constexpr int BV_ = BNRED ? VEC : 1;
+  float bsg[BV_], bsx[BV_], bsx2[BV_], bmean[BV_], binv[BV_], bms[BV_], bmh[BV_], bmean2[BV_], binv2[BV_];
+  if constexpr (BNRED) {
+    const int nc = n0 + (tid % VR) * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const bool ok = nc + j < p.N;
+      bsg[j] = bsx[j] = bsx2[j] = 0.f;
+      bmean[j] = ok ? p.bn_coef[2 * p.N + nc + j] : 0.f; binv[j] = ok ? p.bn_coef[3 * p.N + nc + j] : 0.f;
+      bms[j] = (ok && p.bn_self) ? p.bn_coef[nc + j] : 0.f; bmh[j] = (ok && p.bn_self) ? p.bn_coef[p.N + nc + j] : 0.f;
+      bmean2[j] = (ok && bny2T) ? p.bn_coef2[2 * p.N + nc + j] : 0.f; binv2[j] = (ok && bny2T) ? p.bn_coef2[3 * p.N + nc + j] : 0.f;
     }
-    Vec16<T> v; v.raw = *reinterpret_cast<const u32x4*>(&Cs[row * LDC + (tid % VR) * VEC]);
-    const size_t off = (size_t)m * p.N + n;
-    if (vec_ok) {
-      if (addT) {
-        Vec16<T> av = ldg16(addT + off);
-        if (mskT) {
-          Vec16<T> mv = ldg16(mskT + off);
+  }
+  // The thread's rows are handled in chunks of CHR: ALL global loads of a chunk (addend, masks, BatchNorm operand) are issued
+  // before its first store -- a load behind a store to a possibly aliasing pointer waits for it, and eight dependent
+  // load -> store round trips per tile were a third of the data-gradient launches' time.
+  constexpr int NR = BM / RP, CHR = NR < 4 ? NR : 4;
+  static_assert(BM % RP == 0 && NR % CHR == 0, "epilogue row chunks");
+  const int n = n0 + (tid % VR) * VEC;
+  for (int r0 = 0; r0 < NR; r0 += CHR) {
+    size_t offs[CHR]; bool live[CHR];
+    Vec16<T> av[CHR], mv[CHR], ov[CHR], y2v[BNRED ? CHR : 1];
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + (mv.get(j) > 0.f ? av.get(j) : 0.f));
-        } else {
+    for (int i = 0; i < CHR; ++i) {
+      const int row = tid / VR + (r0 + i) * RP;
+      int m = m0 + row;
+      live[i] = m < row_limit && n < p.N;
+      if (LOADER == LOADER_DGRAD2 && live[i]) {
+        const int b = fast_div(m, p.mul_howo), rem = m - b * Hh * Wh, hh = fast_div(rem, p.mul_wo), ww = rem - hh * Wh;
+        m = (b * p.Ho + 2 * hh + (cls >> 1)) * p.Wo + 2 * ww + (cls & 1);
+      }
+      offs[i] = (size_t)m * p.N + n;
+      if (live[i] && vec_ok) {
+        if (addT) av[i] = ldg16(addT + offs[i]);
+        if (addT && mskT) mv[i] = ldg16(mskT + offs[i]);
+        if (omT) ov[i] = ldg16(omT + offs[i]);
+        if constexpr (BNRED) { if (bny2T) y2v[i] = ldg16(bny2T + offs[i]); }
+      }
+    }
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + av.get(j));
+    for (int i = 0; i < CHR; ++i) {
+      if (!live[i]) continue;
+      const int row = tid / VR + (r0 + i) * RP;
+      const size_t off = offs[i];
+      Vec16<T> v; v.raw = *reinterpret_cast<const u32x4*>(&Cs[row * LDC + (tid % VR) * VEC]);
+      if (vec_ok) {
+        if (addT) {
+          if (mskT) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + (mv[i].get(j) > 0.f ? av[i].get(j) : 0.f));
+          } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) + av[i].get(j));
+          }
+        }
+        if (p.relu == 2) {                             // ReLU AFTER the addend: relu(conv + bias + residual), the folded eval block
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { const float x = v.get(j); v.set(j, x < 0.f ? 0.f : x); }
+        }
+        if (omT) {                                     // data gradient handed to the previous block already masked by ITS ReLU
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) if (!(ov[i].get(j) > 0.f)) v.set(j, 0.f);
+        }
+        stg16(outT + off, v);
+        if constexpr (BNRED) {                         // sums over the values exactly as stored (v is already rounded to T)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float gq = v.get(j);
+            const float yy = ypre[r0 + i].get(j);
+            if (p.bn_self && !(yy * bms[j] + bmh[j] > 0.f)) gq = 0.f;
+            bsg[j] += gq;
+            bsx[j] += gq * (yy - bmean[j]) * binv[j];
+            if (bny2T) bsx2[j] += gq * (y2v[i].get(j) - bmean2[j]) * binv2[j];
+          }
+        }
+      } else {
+        for (int j = 0; j < VEC && n + j < p.N; ++j) {
+          float x = v.get(j);
+          if (addT) { float a = to_f<T>(addT[off + j]); x += (!mskT || to_f<T>(mskT[off + j]) > 0.f) ? a : 0.f; }
+          if (p.relu == 2 && x < 0.f) x = 0.f;
+          if (omT && !(to_f<T>(omT[off + j]) > 0.f)) x = 0.f;
+          outT[off + j] = from_f<T>(x);
         }
       }
-      if (p.relu == 2) {                               // ReLU AFTER the addend: relu(conv + bias + residual), the folded eval block
+    }
+  }
+  if constexpr (BNRED) {
+    // lanes VR apart hold the same columns: fold them inside the wave, then the NW waves through LDS, in a fixed order
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { const float x = v.get(j); v.set(j, x < 0.f ? 0.f : x); }
-      }
-      if (omT) {                                       // data gradient handed to the previous block already masked by ITS ReLU
-        Vec16<T> ov = ldg16(omT + off);
+    for (int j = 0; j < VEC; ++j)
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) if (!(ov.get(j) > 0.f)) v.set(j, 0.f);
+      for (int o = VR; o < 64; o <<= 1) {
+        bsg[j] += __shfl_xor(bsg[j], o, 64); bsx[j] += __shfl_xor(bsx[j], o, 64); bsx2[j] += __shfl_xor(bsx2[j], o, 64);
       }
-      stg16(outT + off, v);
-    } else {
-      for (int j = 0; j < VEC && n + j < p.N; ++j) {
-        float x = v.get(j);
-        if (addT) { float a = to_f<T>(addT[off + j]); x += (!mskT || to_f<T>(mskT[off + j]) > 0.f) ? a : 0.f; }
-        if (p.relu == 2 && x < 0.f) x = 0.f;
-        if (omT && !(to_f<T>(omT[off + j]) > 0.f)) x = 0.f;
-        outT[off + j] = from_f<T>(x);
+    float* red2 = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN, BK, ST, WIN>::CST);     // [NW][3][BN] floats
+    static_assert(NW * 3 * BN * 4 <= IGemmCfg<T, BM, BN, BK, ST, WIN>::SMEM - IGemmCfg<T, BM, BN, BK, ST, WIN>::CST, "bn scratch");
+    __syncthreads();                                   // the statistics scratch / C staging reads are done
+    {
+      if (lane < VR) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          red2[(wave * 3 + 0) * BN + lane * VEC + j] = bsg[j];
+          red2[(wave * 3 + 1) * BN + lane * VEC + j] = bsx[j];
+          red2[(wave * 3 + 2) * BN + lane * VEC + j] = bsx2[j];
+        }
+      }
+      __syncthreads();
+      for (int o = tid; o < 3 * BN; o += NTHR) {
+        const int k = o / BN, c = o - k * BN;
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a += red2[(w * 3 + k) * BN + c];
+        if (n0 + c < p.N) p.bn_slab[((size_t)tile_m * 3 + k) * p.N + n0 + c] = a;
       }
     }
   }
@@ -1190,16 +1290,16 @@ __global__ void fold_bn_batch_kernel(const float* __restrict__ flat, T* __restri
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2, int WIN = 0>
+template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2, int WIN = 0, bool BNRED = false>
 static int launch_igemm(const IGemmParams& p, hipStream_t st) {
   constexpr int SMEM = IGemmCfg<T, BM, BN, BK, ST, WIN>::SMEM;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST, WIN, BNRED>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST, WIN>), dim3(tiles), dim3(NW * 64), SMEM, st, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST, WIN, BNRED>), dim3(tiles), dim3(NW * 64), SMEM, st, p);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }
@@ -1243,6 +1343,18 @@ template <typename T>
 static int igemm_dispatch(const IGemmParams& p, int loader, hipStream_t st) {
   const int v = igemm_variant(p, loader, sizeof(T) == 2);
   if (loader == LOADER_STEM) return launch_igemm<T, 128, 64, LOADER_STEM>(p, st);
+  if (p.bn_slab) {                                 // data gradient + fused BatchNorm-backward reduction
+    if constexpr (sizeof(T) == 2) {
+      if (v == 128 * 10000 + 128 * 10 + 1) return launch_igemm<T, 128, 128, LOADER_NHWC, 4, 64, 2, 2, 1, true>(p, st);
+      if (v == 128 * 10000 + 64 * 10 + 1) return launch_igemm<T, 128, 64, LOADER_NHWC, 4, 64, 2, 2, 1, true>(p, st);
+    }
+    switch (v) {
+      case 128 * 10000 + 128 * 10: return launch_igemm<T, 128, 128, LOADER_NHWC, 4, GT<T>::BK, 2, 2, 0, true>(p, st);
+      case 128 * 10000 + 64 * 10: return launch_igemm<T, 128, 64, LOADER_NHWC, 4, GT<T>::BK, 2, 2, 0, true>(p, st);
+      case 64 * 10000 + 64 * 10: return launch_igemm<T, 64, 64, LOADER_NHWC, 4, GT<T>::BK, 2, 2, 0, true>(p, st);
+      default: return VQA_EARG;                    // (opt-in measurement shapes have no fused-reduction build)
+    }
+  }
   if constexpr (sizeof(T) == 2) {
     switch (v) {
       case 128 * 10000 + 128 * 10 + 1: return launch_igemm<T, 128, 128, LOADER_NHWC, 4, 64, 2, 2, 1>(p, st);
@@ -1389,8 +1501,10 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
               const void* addend, const void* addmask, const void* outmask, float* stats,
               int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
+              const void* bn_y, const float* bn_coef, const void* bn_y2, const float* bn_coef2, float* bn_slab, int bn_self,
               hipStream_t st) {
   if (M <= 0 || N <= 0 || !a || !w || !out) return VQA_EARG;
+  if (bn_slab && (!bn_y || !bn_coef || (bn_y2 && !bn_coef2) || (N % (dtype ? 8 : 4)) || loader != LOADER_NHWC)) return VQA_EARG;
   const int VEC = dtype ? 8 : 4, BK = dtype ? 64 : 32;
   if (loader == LOADER_NHWC) {
     if (C % VEC) return VQA_EARG;
@@ -1406,6 +1520,7 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
   p.M = M; p.N = N; p.Kw = Kw; p.Kp = (Kw + BK - 1) / BK * BK;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
   p.transposed = transposed; p.relu = relu; p.drop_p = drop_p; p.drop_seed = drop_seed; p.a2 = nullptr;
+  p.bn_y = bn_y; p.bn_coef = bn_coef; p.bn_y2 = bn_y2; p.bn_coef2 = bn_coef2; p.bn_slab = bn_slab; p.bn_self = bn_self;
   {
     const size_t es = dtype ? 2 : 4;
     const size_t ab = (size_t)B * H * W * C * es, wb = (size_t)N * Kw * es;
@@ -1434,6 +1549,7 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
   if (!dy || !wt || !out || (Ho & 1) || (Wo & 1) || C % BK || N % VEC || R > 3 || R < 1) return VQA_EARG;
   IGemmParams p;
   p.a = dy; p.a2 = dyd; p.w = wt; p.out = out; p.bias = nullptr; p.addend = nullptr; p.addmask = nullptr; p.stats = nullptr; p.outmask = nullptr;
+  p.bn_y = nullptr; p.bn_coef = nullptr; p.bn_y2 = nullptr; p.bn_coef2 = nullptr; p.bn_slab = nullptr; p.bn_self = 0;
   p.N = N; p.Kw = R * R * C + (dyd ? C : 0); p.Kp = p.Kw; p.M = B * Ho * Wo;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = R; p.stride = 2; p.pad = pad;
   p.transposed = 1; p.relu = 0; p.drop_p = 0.f; p.drop_seed = 0;

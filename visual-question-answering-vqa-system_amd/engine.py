@@ -42,6 +42,10 @@ class HipEngine:
         self._wt_table = None
         self._wt_buf = None
         self.defer_tail = os.environ.get("VQA_DEFER_TAIL", "1") != "0"
+        # BatchNorm-backward column sums reduced inside the data-gradient epilogues (igemm bnred=...): built and parity-tested, but
+        # measured SLOWER in the step (the serial epilogue of a compute-bound tile is a poor place for a streaming reduction:
+        # +0.5 ms of igemm time for 0.4 ms of reduce passes saved at B=512), so it is an opt-in measurement switch
+        self.fuse_bn_reduce = os.environ.get("VQA_BNRED", "0") == "1"
         self._deferred = []
         self._stem_fcoef = None
         self.fold_eval = True                     # inference (eval, no tape): Conv+BN folded, BN never runs as its own pass
@@ -703,12 +707,14 @@ class HipEngine:
             else:
                 masked = False
             nb = len(srec["blocks"])
+            pre = None           # BatchNorm-backward sums of the next block's bn2, already reduced by the epilogue that produced dxc
             for bi in range(nb - 1, -1, -1):
                 rec = srec["blocks"][bi]
-                # the gradient handed to the previous block of the stage is masked by THAT block's ReLU in this block's epilogue
-                hand_mask = rec["x"] if (bi > 0 and "yd" not in rec) else None
-                dxc = self._block_bwd(rec, dxc, G, training, masked=masked, outmask=hand_mask)
-                masked = hand_mask is not None
+                # the gradient handed to the previous block of the stage is masked by THAT block's ReLU in this block's epilogue,
+                # which also reduces that block's bn2-backward sums (it holds the finished gradient tile anyway)
+                hand = srec["blocks"][bi - 1] if (bi > 0 and "yd" not in rec) else None
+                dxc, pre = self._block_bwd(rec, dxc, G, training, masked=masked, hand=hand, pre=pre)
+                masked = hand is not None
             if not self._deferred:                # stage 1: its held-back weight gradients are released below, report it there
                 seg(f"image_encoder.stage{s}")
 
@@ -772,10 +778,13 @@ class HipEngine:
             K.wgrad(dy, st["images"], LY.mat_of(G, self.E["image_encoder.stem.0.weight"]), B * H1 * W1, 64, 147, st["geom"], dtype=T,
                     loader=K.LOADER_STEM)
 
-    def _block_bwd(self, rec, dout, G, training, masked=False, outmask=None):
-        """ResidualBlock backward (reference forward: models/cnn_backbone.py:164-197).
+    def _block_bwd(self, rec, dout, G, training, masked=False, hand=None, pre=None):
+        """ResidualBlock backward (reference forward: models/cnn_backbone.py:164-197).  Returns (dx, pre-reduced bn2 sums for `hand`).
         masked: `dout` was already multiplied by (out > 0) by its producer, so the block output is never re-read here.
-        outmask: activation whose sign masks the returned gradient (the previous block's post-ReLU output = this block's input)."""
+        hand: tape record of the PREVIOUS block of the stage (this block's input is its post-ReLU output): the returned gradient
+              is masked by that ReLU and the previous block's bn2-backward column sums are reduced in the same epilogue.
+        pre: (slab, rows) of this block's bn2-backward sums when the producer of `dout` already reduced them."""
+        outmask = hand["out"] if hand is not None else None
         T = self.dtype
         p, Cout, Cin, M = rec["p"], rec["Cout"], rec["Cin"], rec["M"]
         has_ds = "yd" in rec
@@ -787,20 +796,27 @@ class HipEngine:
                             y2=rec.get("yd"), coef2=rec.get("cd"),
                             gamma2=self.P(p + ".downsample.1.weight") if has_ds else None,
                             dgamma2=gs(p + ".downsample.1.weight") if has_ds else None,
-                            dbeta2=gs(p + ".downsample.1.bias") if has_ds else None)
+                            dbeta2=gs(p + ".downsample.1.bias") if has_ds else None,
+                            slab=pre[0] if pre else None, nb=pre[1] if pre else 0)
         g2 = rec["g2"]; B, Ho, Wo = g2[0], g2[1], g2[2]
         c64_2 = self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1)
         if self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1, wgrad=True):
             self._off_path([dy2], lambda: K.wgrad3x3_c64(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo), defer=last)
         else:
             self._off_path([dy2], lambda: K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T))
+        slab1, nb1 = None, 0
         if c64_2:
             da1, _, _ = K.conv3x3_c64(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
         else:
             geom_d2 = (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
-            da1, _, _ = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1)
+            # bn1's backward column sums (g = da1 * [relu(bn1(y1)) > 0]) are reduced in this launch's epilogue
+            da1, slab1, nb1 = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1,
+                                      bnred=(rec["y1"], rec["c1"], True) if self.fuse_bn_reduce else None)
+            if not self.fuse_bn_reduce:
+                slab1, nb1 = None, 0
         dy1, _ = K.bn_bwd(da1, None, rec["y1"], rec["c1"], self.P(p + ".bn1.weight"), Cout, training,
-                          gs(p + ".bn1.weight"), gs(p + ".bn1.bias"), self_mask=True)      # a1 > 0 recomputed from y1: a1 is not read
+                          gs(p + ".bn1.weight"), gs(p + ".bn1.bias"), self_mask=True,      # a1 > 0 recomputed from y1: a1 is not read
+                          slab=slab1, nb=nb1)
         g1 = rec["g1"]; H, W, stride = g1[1], g1[2], g1[8]
         c64_1 = self._c64_ok(B, H, W, Cin, Cout, 3, stride)
         if self._c64_ok(B, H, W, Cin, Cout, 3, stride, wgrad=True):
@@ -824,6 +840,11 @@ class HipEngine:
         elif c64_1 and not masked and outmask is None:
             dx, _, _ = K.conv3x3_c64(dy1, self._wflip(p + ".conv1.weight"), B, H, W, addend=dout, addmask=rec["out"])
         else:
-            dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
-                               addend=dout, addmask=out_act, outmask=outmask)
-        return dx
+            bnred = None
+            if hand is not None and self.fuse_bn_reduce:      # previous block's bn2 (and its 1x1-shortcut BN): sums reduced here
+                bnred = (hand["y2"], hand["c2"], False) + ((hand["yd"], hand["cd"]) if "yd" in hand else ())
+            dx, slabp, nbp = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
+                                     addend=dout, addmask=out_act, outmask=outmask, bnred=bnred)
+            if bnred is not None:
+                return dx, (slabp, nbp)
+        return dx, None
