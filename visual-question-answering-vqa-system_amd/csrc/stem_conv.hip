@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 // (contraction index = pixel).  Partial dW stays in registers over the whole walk; one atomic flush per workgroup.
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr int RBW = 2;             // output rows per block
+constexpr int RBW = 4;             // output rows per block (2 measured 12 % slower, 0.98 vs 0.86 ms at B=512: 9 input rows and one patch-load barrier per 2 output rows)
 constexpr int PRW = 2 * RBW + 5;   // patch rows
 constexpr int LDA = KP + 8;        // im2col row stride
 constexpr int LDD = 64 + 4;        // dy row stride
