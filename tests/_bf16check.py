@@ -5,7 +5,8 @@ the CPU oracle under PyTorch's own bf16 autocast sits at relative errors e = |g 
 tensor at B=8 (cosine 0.85-0.93), while the HIP fp32 path is at cosine 1.0000 everywhere (tools/diag_bf16_grads.py).  So the
 HIP bf16 gradients are held to the measured noise floor of the same model in torch's bf16:
     every tensor:        e_hip <= 1.25 * e_autocast + 0.10
-    weights (>= 2 dims): e_hip <= 0.75         (a wrong tile, halo mask or permutation gives e >= 1)
+    weights (>= 2 dims): e_hip <= 0.75         (a wrong tile, halo mask or permutation gives e >= 1) wherever torch's own bf16 run
+                         is below 0.6 -- the 98-element spatial-attention conv sits at e_autocast ~ 1.2 and is held to the first bound only
     whole-model vector:  e_hip <= 1.15 * e_autocast + 0.02
 except `noisy` tensors (squeeze-excitation fc1 of the early stages, 4x64 ... 16x256 matrices: their gradient is the global
 average of dout*x over 3136 ... 196 positions, a sum with near-total cancellation of bf16-STORED gradients; both bf16
@@ -45,8 +46,8 @@ def check_bf16_grads(model, sd, cfg, images, ids, mask, answers, noisy=()):
             assert 0.25 < ratio < 4.0, (n, ratio)
             continue
         assert e_hip <= 1.25 * e_acb + 0.10, (n, e_hip, e_acb, "worst", worst)
-        if dim >= 2:
-            assert e_hip <= 0.75, (n, e_hip, "worst", worst)
+        if dim >= 2 and e_acb <= 0.6:
+            assert e_hip <= 0.75, (n, e_hip, e_acb, "worst", worst)
     G, R, A = (torch.cat([d[n] for n in names]) for d in (got, ref, acb))
     assert float((G - R).norm() / R.norm()) <= 1.15 * float((A - R).norm() / R.norm()) + 0.02
     return worst, lref

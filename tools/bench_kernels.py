@@ -48,6 +48,8 @@ for name, Cin, Cout, H, R, stride, pad in CONVS:
     fl = 2.0 * M * Cout * Kw
     t = timeit(lambda: K.igemm(x, wp, M, Cout, Kw, geom, dtype=T, want_stats=True), args.iters)
     print(f"{name:22s} fwd   {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   io {(x.numel()+M*Cout)*2/t/1e12:5.2f} TB/s")
+    t = timeit(lambda: K.igemm(x, wp, M, Cout, Kw, geom, dtype=T, want_stats=False), args.iters)
+    print(f"{name:22s} fwd-ns{t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   (no BN statistics)")
     t = timeit(lambda: K.igemm(dy, wt, B * H * H, Cin, R * R * Cout, geom_d, dtype=T, transposed=1), args.iters)
     print(f"{name:22s} dgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
     t = timeit(lambda: K.wgrad(dy, x, dw, M, Cout, Kw, geom, dtype=T), args.iters)

@@ -529,8 +529,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
         }
   }
   // ---- BatchNorm partial statistics (sum, sum of squares per output channel of this M tile) ----
+  // fp32: DPP row reductions of the accumulators.  bf16: done on the matrix cores AFTER the C tile is staged (below) -- the
+  // VALU form cost 26 % of the stage-1 forward convs (K = 576: nine K steps per tile, so the epilogue weighs heavily).
   float* red = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN, BK, ST, WIN>::CST);   // [WM][BN][2], after the C staging area (tiles are dead by now)
-  if (p.stats) {
+  if (p.stats && sizeof(T) == 4) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -565,7 +567,36 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
       }
     }
   __syncthreads();
-  if (p.stats && tid < BN) {
+  if constexpr (sizeof(T) == 2) {
+    if (p.stats) {
+      // Column sums and sums of squares of the staged bf16 tile Y [BM][BN] as two MFMA chains per 16-column block: with the
+      // transposed fragment F (lane: column l&15, 8 consecutive rows) as BOTH operands, D = F^T F is the Gram block whose diagonal
+      // is sum y^2, and ones^T F gives sum y in every row.  Exact fp32 accumulation of the values as stored (rows past M are zero).
+      typedef __attribute__((ext_vector_type(8))) short i16x8;
+      constexpr int CB = BN / 16;
+      const int sg = lane >> 4, sli = lane & 15, sq = sli >> 2, spp = sli & 3;
+      const i16x8 ones_i = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+      const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_i);
+      for (int cb = wave; cb < CB; cb += NW) {              // wave-uniform: EXEC stays full for the transposed reads
+        f32x4 dsum = {0.f, 0.f, 0.f, 0.f}, dsq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < BM / 32; ++ks) {
+          const T* bp = Cs + (ks * 32 + 8 * sg + sq) * LDC + cb * 16 + 4 * spp;
+          i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(bp));
+          i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(bp + 4 * LDC));
+          i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const bf16x8 yf = __builtin_bit_cast(bf16x8, t);
+          dsq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, yf, dsq, 0, 0, 0);
+          dsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf, dsum, 0, 0, 0);
+        }
+        const int n = n0 + cb * 16 + sli;                     // D[i][j]: lane holds column j = l&15, rows 4*(l>>4) + r
+        if (n < p.N) {
+          if (sg == 0) p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = dsum[0];
+          if (sg == sq) p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = spp == 0 ? dsq[0] : spp == 1 ? dsq[1] : spp == 2 ? dsq[2] : dsq[3];
+        }
+      }
+    }
+  } else if (p.stats && tid < BN) {
     const int n = n0 + tid;
     if (n < p.N) {
       float s = 0.f, q = 0.f;
@@ -1307,7 +1338,9 @@ static int launch_igemm(const IGemmParams& p, hipStream_t st) {
 static void igemm_tile(int M, int N, int* bm, int* bn) {
   static int bm_env = -1;
   if (bm_env < 0) { const char* e = getenv("VQA_IGEMM_BM"); bm_env = e ? atoi(e) : 128; }
-  if (N <= 64) { *bn = 64; *bm = 128; }      // (256-row tiles were measured slower for the 64-channel layers)
+  static int bm64_env = -1;
+  if (bm64_env < 0) { const char* e = getenv("VQA_IGEMM_BM64"); bm64_env = e ? atoi(e) : 128; }
+  if (N <= 64) { *bn = 64; *bm = (bm64_env == 256 && M >= 256 * 256) ? 256 : 128; }      // (256-row tiles were measured slower for the 64-channel layers)
   else { *bn = 128; *bm = (bm_env >= 256 && M >= 256 * 256) ? 256 : 128; }   // 256 / 257: opt-in 8-wave 256x128 tile (2 / 3 slots)
   long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
   if (tiles < 384) { *bm = 64; *bn = 64; }
@@ -1324,6 +1357,9 @@ static int igemm_variant(const IGemmParams& p, int loader, bool bf16) {
     if (win_env && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.H == p.Ho && p.W == p.Wo && p.C % 64 == 0 && bm == 128 &&
         (long)p.B * p.H * p.W == (long)p.M)
       return 128 * 10000 + bn * 10 + 1;
+    if (win_env && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.H == p.Ho && p.W == p.Wo && p.C % 64 == 0 && bm == 256 && bn == 64 &&
+        (long)p.B * p.H * p.W == (long)p.M)
+      return 256 * 10000 + 64 * 10 + 1;
   }
   if (bm == 256 && bn == 128) {
     if (!bf16) return 128 * 10000 + 128 * 10;
@@ -1359,6 +1395,7 @@ static int igemm_dispatch(const IGemmParams& p, int loader, hipStream_t st) {
     switch (v) {
       case 128 * 10000 + 128 * 10 + 1: return launch_igemm<T, 128, 128, LOADER_NHWC, 4, 64, 2, 2, 1>(p, st);
       case 128 * 10000 + 64 * 10 + 1: return launch_igemm<T, 128, 64, LOADER_NHWC, 4, 64, 2, 2, 1>(p, st);
+      case 256 * 10000 + 64 * 10 + 1: return launch_igemm<T, 256, 64, LOADER_NHWC, 8, 64, 2, 2, 1>(p, st);
       case 256 * 10000 + 128 * 10 + 2: return launch_igemm<T, 256, 128, LOADER_NHWC, 8, 64, 2, 2>(p, st);
       case 256 * 10000 + 128 * 10 + 3: return launch_igemm<T, 256, 128, LOADER_NHWC, 8, 64, 2, 3>(p, st);
       case 128 * 10000 + 128 * 10 + 4: return launch_igemm<T, 128, 128, LOADER_NHWC, 2, 32>(p, st);
