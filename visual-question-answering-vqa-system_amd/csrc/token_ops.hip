@@ -381,6 +381,54 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
   (void)relu_drop;
 }
 
+// Vectorised form of bias_act_bwd_kernel for N % 8 == 0 (bf16) / N % 4 == 0 (fp32): a thread owns one 16-byte column group and
+// walks the rows of its strip (the scalar kernel above issues 2-byte loads: 18 us per call on tensors a few MB large).
+// dbias: per-thread partial sums, folded over the block's row lanes in LDS, one atomic per column per block.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_bwd_vec_kernel(const T* __restrict__ dout, const T* __restrict__ outact, T* __restrict__ dz,
+                                                               float* dbias, int M, int N, float p, uint64_t seed, int rows_per) {
+  constexpr int VEC = Vec16<T>::N;
+  const int cvs = N / VEC;                                   // column groups per row
+  const int gpb = cvs < 256 ? cvs : 256;                     // column groups handled by one block (per blockIdx.x)
+  const int lanes_r = 256 / gpb;                             // rows in flight per block pass
+  const int cg = blockIdx.x * gpb + threadIdx.x % gpb, rl = threadIdx.x / gpb;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float s[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t dkey = drop_key(seed);
+  if (cg < cvs && rl < lanes_r) {
+#pragma unroll 2
+    for (int r = r0 + rl; r < r1; r += lanes_r) {
+      const size_t o = (size_t)r * N + (size_t)cg * VEC;
+      Vec16<T> d = ldg16(dout + o), a, z;
+      if (outact) a = ldg16(outact + o);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float g = d.get(j);
+        if (outact) { if (!(a.get(j) > 0.f)) g = 0.f; else g *= ks; }          // relu(+dropout): out > 0 encodes both masks
+        else if (p > 0.f) g = drop_keep32(dkey, (uint32_t)(o + j), p) ? g * ks : 0.f;
+        z.set(j, g);
+        s[j] += g;
+      }
+      if (dz) stg16(dz + o, z);
+    }
+  }
+  if (!dbias) return;
+  __shared__ float sh[256 * VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sh[threadIdx.x * VEC + j] = s[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < gpb * VEC; c += 256) {
+    const int gq = c / VEC, j = c - gq * VEC;
+    float t = 0.f;
+    for (int r = 0; r < lanes_r; ++r) t += sh[(r * gpb + gq) * VEC + j];
+    const int col = (blockIdx.x * gpb + gq) * VEC + j;
+    if (col < N) atomicAdd(dbias + col, t);
+  }
+}
+
 // cross entropy (mean) forward+backward in one pass: wave per row
 template <typename T>
 __global__ void cross_entropy_kernel(const T* __restrict__ logits, const long long* __restrict__ targets, float* loss, T* __restrict__ dlogits,
@@ -569,6 +617,18 @@ int vqa_add(int dtype, const void* a, const void* b, void* out, long long n, hip
 }
 // outact != null: relu (and dropout folded into out>0); outact == null && p>0: dropout mask regenerated from (seed, index)
 int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, float* dbias, int M, int N, float p, unsigned long long seed, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  if (N % VEC == 0 && M > 0 && (256 % (N / VEC < 256 ? N / VEC : 256)) == 0) {
+    const int cvs = N / VEC, gpb = cvs < 256 ? cvs : 256, lanes_r = 256 / gpb;
+    int gy = (M + 16 * lanes_r - 1) / (16 * lanes_r);        // ~16 row passes per block; <= 1024 blocks in y
+    if (gy > 1024) gy = 1024;
+    if (gy < 1) gy = 1;
+    const int rows_per = (M + gy - 1) / gy;
+    dim3 grid((cvs + gpb - 1) / gpb, (M + rows_per - 1) / rows_per);
+    DT(hipLaunchKernelGGL(bias_act_bwd_vec_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)outact, (float*)dz, dbias, M, N, p, seed, rows_per),
+       hipLaunchKernelGGL(bias_act_bwd_vec_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (bf16_t*)dz, dbias, M, N, p, seed, rows_per));
+    VQA_LAUNCH_CHECK(); return VQA_OK;
+  }
   int gy = (M + 127) / 128; if (gy > 256) gy = 256; if (gy < 1) gy = 1;
   dim3 grid((N + 63) / 64, gy);
   DT(hipLaunchKernelGGL(bias_act_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)outact, (float*)dz, dbias, M, N, 0, p, seed),
