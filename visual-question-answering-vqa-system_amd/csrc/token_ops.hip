@@ -62,6 +62,51 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
 }
 
+// bf16, D = 8 * LPR with LPR = 8 / 16 / 32 / 64 lanes per row: a lane owns one 16-byte segment of its row (one load, one store),
+// 64 / LPR rows per wave; mean / variance are sub-wave shuffle reductions.  Same arithmetic as layernorm_fwd_kernel.
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_fwd_bf16v_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, bf16_t* __restrict__ out, float* __restrict__ stats,
+                                                                  int rows, float eps, float p, uint64_t seed, const float* __restrict__ addrow, int period) {
+  constexpr int D = LPR * 8, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, sl = lane % LPR;
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  const int c0 = sl * 8;
+  float gm[8], bt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j]; }
+  const uint32_t dkey = drop_key(seed);
+  const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int r0 = wid * RPW; r0 < rows; r0 += nw * RPW) {
+    const int row = r0 + sub;
+    const bool live = row < rows;
+    Vec16<bf16_t> v = live ? ldg16(x + (size_t)row * D + c0) : zero16<bf16_t>();
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v.get(j);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float t = v.get(j) - mean; q += t * t; }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)D + eps);
+    if (!live) continue;
+    if (sl == 0 && stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    Vec16<bf16_t> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = (v.get(j) - mean) * rstd * gm[j] + bt[j];
+      if (p > 0.f) y = drop_keep32(dkey, (uint32_t)((uint64_t)row * D + c0 + j), p) ? y * ks : 0.f;
+      if (addrow) y += addrow[(size_t)(row % period) * D + c0 + j];
+      o.set(j, y);
+    }
+    stg16(out + (size_t)row * D + c0, o);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ stats, const T* __restrict__ addend, T* __restrict__ dx,
@@ -539,6 +584,14 @@ int vqa_embed_bwd(int dtype, const long long* ids, const void* dout, float* demb
 int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* stats, int rows, int D, float eps,
                       float p, unsigned long long seed, const float* addrow, int period, hipStream_t st) {
   if (D > 512 || rows <= 0) return VQA_EARG;
+  if (dtype && (D == 64 || D == 128 || D == 256 || D == 512)) {
+    const int rpw = 512 / D, waves = (rows + rpw - 1) / rpw;
+    const int g = (waves + 3) / 4 > 2048 ? 2048 : (waves + 3) / 4;
+#define LNV(L) hipLaunchKernelGGL(layernorm_fwd_bf16v_kernel<L>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)out, stats, rows, eps, p, seed, addrow, period)
+    if (D == 64) LNV(8); else if (D == 128) LNV(16); else if (D == 256) LNV(32); else LNV(64);
+#undef LNV
+    VQA_LAUNCH_CHECK(); return VQA_OK;
+  }
   const int grid = (rows + 3) / 4 > 2048 ? 2048 : (rows + 3) / 4;
   DT(hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)out, stats, rows, D, eps, p, seed, addrow, period),
      hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)out, stats, rows, D, eps, p, seed, addrow, period));
