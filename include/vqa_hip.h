@@ -62,6 +62,10 @@ int vqa_fold_bn_batch(int dtype, const float* flat, void* wout, float* bout, con
 int vqa_conv3x3_c64_blocks(int B, int H, int W);
 int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const void* addend, const void* addmask,
                     int B, int H, int W, hipStream_t stream);
+/* same conv (forward, or data gradient with the flipped pack) without epilogue inputs: 8-wave persistent kernel, 8 output rows per
+ * block, input patches by LDS-DMA, weights in registers; stats [vqa_conv3x3_c64p_blocks][2][64] or NULL.  H % 8 == 0, W % 8 == 0. */
+int vqa_conv3x3_c64p_blocks(int B, int H, int W);
+int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, hipStream_t stream);
 int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw /* [64][576] += */, int B, int H, int W,
                      float* ws /* >= vqa_conv3x3_c64_blocks * 64*576 floats of scratch, or NULL: atomics */, long long ws_floats, hipStream_t stream);
 /* second pass of the deterministic split weight gradients: dw[i] += sum_s ws[s][i] in slab order (n % 4 == 0) */

@@ -265,3 +265,34 @@ def test_pack_transpose_batch_matches_single_launches():
         for d0, c, ld, col0, width, ref in refs:
             got = out[d0: d0 + c * ld].view(c, ld)
             assert torch.equal(got[:, col0: col0 + width], ref[:, col0: col0 + width])
+
+
+@pytest.mark.parametrize("case", [(2, 56, 56), (3, 16, 24), (1, 8, 8), (40, 56, 56), (5, 24, 16)])
+def test_conv3x3_c64_dma_patch_kernel(case):
+    """8-wave persistent patch kernel with LDS-DMA patches (stage-1 forward / addend-free data gradient, bf16): output and BN partial
+    statistics against ATen, forward weights and the flipped-transposed pack; (40, 56, 56) gives 280 blocks on the 256-workgroup
+    persistent grid, i.e. workgroups that walk two blocks through both patch buffers."""
+    K = sub("kernels")
+    B, H, W = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(H * 11 + W + B)
+    x = _round(torch.randn(B, 64, H, W, generator=g), dtype)
+    w = _round(torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5, dtype)
+    dy = _round(torch.randn(B, 64, H, W, generator=g), dtype)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, None, stride=1, padding=1)
+    yr.backward(dy)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    w_krsc = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    assert K.c64p_blocks(B, H, W) == min(B * H // 8, 256)
+    y, stats, nb = K.conv3x3_c64p(nhwc(x), K.pack_rows(w_krsc.view(64, 576), dtype), B, H, W, want_stats=True)
+    torch.cuda.synchronize()
+    y_ref = yr.detach().permute(0, 2, 3, 1).reshape(-1, 64)
+    assert _relerr(y.float().cpu(), y_ref) < _tol(dtype)
+    s = stats.sum(0).cpu()
+    assert _relerr(s[0], y_ref.sum(0)) < 5e-3 and _relerr(s[1], (y_ref ** 2).sum(0)) < 5e-3
+    wflip = K.pack_transpose(w_krsc.view(64, 9, 64), dtype, flip=True)
+    dx, _, _ = K.conv3x3_c64p(nhwc(dy), wflip, B, H, W)
+    torch.cuda.synchronize()
+    assert _relerr(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1).reshape(-1, 64)) < _tol(dtype)
+    assert K.c64p_blocks(2, 10, 10) == 0 and K.c64p_blocks(2, 12, 16) == 0          # unsupported shapes are refused, not mangled

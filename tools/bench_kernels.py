@@ -65,6 +65,11 @@ if not args.only or "c64" in args.only:
     fl = 2.0 * B * H * H * 64 * 576
     t = timeit(lambda: K.conv3x3_c64(x, wp, B, H, H, want_stats=True), args.iters)
     print(f"c64 patch conv fwd     {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   io {(2*x.numel())*2/t/1e12:5.2f} TB/s")
+    wfl = K.pack_transpose(w.view(64, 9, 64), T, flip=True)
+    t = timeit(lambda: K.conv3x3_c64p(x, wp, B, H, H, want_stats=True), args.iters)
+    print(f"c64 DMA patch conv fwd {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   io {(2*x.numel())*2/t/1e12:5.2f} TB/s")
+    t = timeit(lambda: K.conv3x3_c64p(dy, wfl, B, H, H), args.iters)
+    print(f"c64 DMA patch dgrad    {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
     t = timeit(lambda: K.wgrad3x3_c64(x, dy, dw, B, H, H), args.iters)
     print(f"c64 patch wgrad        {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
 

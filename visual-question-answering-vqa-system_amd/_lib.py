@@ -28,6 +28,8 @@ SIGNATURES = {
     "vqa_fold_bn_batch": [I, P, P, P, P, I, I, F, P],
     "vqa_conv3x3_c64_blocks": [I, I, I],
     "vqa_conv3x3_c64": [P, P, P, P, P, P, I, I, I, P],
+    "vqa_conv3x3_c64p_blocks": [I, I, I],
+    "vqa_conv3x3_c64p": [P, P, P, P, I, I, I, P],
     "vqa_wgrad3x3_c64": [P, P, P, I, I, I, P, LL, P],
     "vqa_slab_reduce": [P, P, I, LL, P],
     "vqa_dgrad_s2": [I, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
@@ -75,7 +77,7 @@ SIGNATURES = {
     "vqa_pack_tokens": [P, P, P, P, I, I, I, I, I, I, P],
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P],
 }
-_NO_STATUS = {"vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
+_NO_STATUS = {"vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
 
 _lib = None
 

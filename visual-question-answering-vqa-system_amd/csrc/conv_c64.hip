@@ -8,6 +8,7 @@
 //   * wgrad: contraction over pixels, both operands via ds_read_b64_tr_b16, 64x576 partial dW in registers over the
 //     whole walk, one atomic flush per workgroup.
 // These layers are HBM-bound in bf16 (288 flop/byte); the patch cuts L2/HBM reads ~9x versus a per-tap gather.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -26,6 +27,7 @@ __device__ __forceinline__ int patch_off(int prow, int pcol, int chunk, int PWc)
 struct C64Params {
   const bf16_t* x; const bf16_t* w; bf16_t* out; float* stats; const bf16_t* addend; const bf16_t* addmask;
   int B, H, W; unsigned x_bytes;
+  int dbg;                        // VQA_C64P_DBG (measurement only, wrong results): bit 0 no epilogue, bit 1 no MFMA loop, bit 2 no in-loop DMA
 };
 
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(C64Params p) {
@@ -159,6 +161,154 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(C64Params p) {
     if (tid < 64) {
       p.stats[((size_t)blockIdx.x * 2) * 64 + tid] = red[tid * 2] + red[(64 + tid) * 2];
       p.stats[((size_t)blockIdx.x * 2 + 1) * 64 + tid] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 2: persistent patch kernel with LDS-DMA patches, 8 waves, 8 output rows per block (forward and the addend-free data
+// gradient of the 64-channel stage).  Why: the generic window-loader tile re-streams the 72 KB weight matrix for every 128-pixel
+// tile (76 FLOP per staged byte) and these launches are bound by the per-CU L2->LDS ingest rate; here
+//   * the weights never touch LDS: each wave keeps the 36 B fragments of its 32 output channels in registers for the launch;
+//   * a block = (image, 8 output rows): its 10 x (W+2) x 64 input patch is brought in ONCE by LDS-DMA (inline asm, hidden from
+//     hipcc's vmcnt bookkeeping: it would drain the prefetch in front of the first ds_read), one 1 KB piece = 8 pixels of a row,
+//     swizzled on the source side, into the buffer the previous block is not reading -> 186 FLOP per staged byte;
+//   * halo columns are zeroed once, halo rows outside the image are out-of-range source offsets;
+//   * no vector-memory LOAD is issued by the computing waves besides the DMA (stores only), so nothing ever waits on the
+//     prefetch before the block-end barrier -- which is why the variant with an identity addend stays on the generic kernel.
+namespace {
+constexpr int RBP = 8;            // output rows per block
+typedef int i32x4_c64 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma16_c64(i32x4_c64 rs, unsigned lds_addr, int voff, int soff) {
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_addr), "s"(soff) : "memory");
+}
+}
+
+__global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int PWc = p.W + 2;
+  const int patch_elems = (RBP + 2) * PWc * CH;
+  bf16_t* patch0 = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* patch1 = patch0 + patch_elems;
+  float* red = reinterpret_cast<float*>(patch1 + patch_elems);  // [4 m-waves][64][2]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;                    // wave owns channels [32*wn, 32*wn+32), m tiles wm, wm+4, ...
+  const int rblocks = p.H / RBP, nblocks = p.B * rblocks;
+  const int mtiles = RBP * p.W / 16;
+  const unsigned long long xa = (unsigned long long)p.x;
+  const i32x4_c64 rsX = {(int)(unsigned)xa, (int)((unsigned)(xa >> 32) & 0xffffu), (int)p.x_bytes, 0x00020000};
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+
+  // ---- weight fragments: w[n][(r,s,c)] (576 per row), resident for the whole launch.  The weights are the MFMA's A operand
+  //      (D = W X^T: a lane ends up with 4 consecutive rows = output channels of ONE pixel), and the fragment's row i is mapped to
+  //      channel 8*(i>>2) + 4*nt + (i&3): the two 16-row tiles together give every lane 8 CONSECUTIVE channels of its pixel, i.e.
+  //      one 16-byte global store per lane straight from the accumulators -- no LDS staging in the epilogue.
+  bf16x8 bfr[18][2];
+#pragma unroll
+  for (int kk = 0; kk < 18; ++kk)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      bfr[kk][nt] = *reinterpret_cast<const bf16x8*>(p.w + (size_t)(wn * 32 + 8 * (li >> 2) + 4 * nt + (li & 3)) * 576 + kk * 32 + g * 8);
+
+  // ---- halo columns of both patch buffers: zero, once (the DMA pieces only ever write columns 1 .. W)
+  for (int i = tid; i < 2 * (RBP + 2) * 2 * 8; i += 512) {
+    const int chunk = i & 7, side = (i >> 3) & 1, prow = (i >> 4) % (RBP + 2), buf = (i >> 4) / (RBP + 2);
+    bf16_t* pt = buf ? patch1 : patch0;
+    *reinterpret_cast<u32x4*>(pt + ((size_t)(prow * PWc + (side ? PWc - 1 : 0)) * 8 + chunk) * 8) = u32x4{0u, 0u, 0u, 0u};
+  }
+  // ---- DMA plan: piece id = prow * ppr + j covers pixels 8j .. 8j+7 of image row (oh0 - 1 + prow); wave w issues ids w, w+8, ...
+  const int ppr = p.W >> 3, npieces = (RBP + 2) * ppr;
+  const int dpx = lane >> 3, dpos = lane & 7;
+  const int dvoff = dpx * 128 + ((dpos ^ ((1 + dpx) & 7)) << 4);      // pixel row + swizzled SOURCE chunk (pcol & 7 == (1 + px) & 7)
+  constexpr int OOB = (int)0x80000000;
+  auto issue_patch = [&](int blk, int buf) {
+    const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBP;
+    const unsigned base = lds0 + (unsigned)buf * (unsigned)(patch_elems * 2);
+    for (int id = wave; id < npieces; id += 8) {
+      const int prow = id / ppr, j = id - prow * ppr, ih = oh0 - 1 + prow;
+      const bool ok = (unsigned)ih < (unsigned)p.H;
+      dma16_c64(rsX, base + (unsigned)((prow * PWc + 1 + 8 * j) * 128), ok ? dvoff : OOB, ok ? ((b * p.H + ih) * p.W + 8 * j) * 128 : 0);
+    }
+  };
+
+  const float inv_w = 1.0f / (float)p.W;
+  float ssum[8], ssq[8];                                        // this lane's 8 channels (32*wn + 8*g + j), summed over its pixels
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  const int tiles_pw = (p.dbg & 1) ? 0 : (mtiles - wm + 3) / 4;   // output stores this wave issues per block (uniform)
+  int blk = blockIdx.x, buf = 0;
+  if (blk < nblocks) issue_patch(blk, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; blk < nblocks; blk += gridDim.x, buf ^= 1) {
+    const int nxt = blk + gridDim.x;
+    if (nxt < nblocks && !(p.dbg & 4)) issue_patch(nxt, buf ^ 1);   // the other buffer: every wave finished reading it at the last barrier
+    const bf16_t* pt = buf ? patch1 : patch0;
+    const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBP;
+    for (int mt = wm; mt < mtiles; mt += 4) {
+      const int px = mt * 16 + li, orow = (int)(((float)px + 0.5f) * inv_w), ow = px - orow * p.W;
+      int e[3][2];
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const int col = ow + s_, cb = (orow * PWc + col) * 64;
+        e[s_][0] = cb + ((g ^ (col & 7)) << 3);
+        e[s_][1] = cb + (((4 + g) ^ (col & 7)) << 3);
+      }
+      const int rowstep = PWc * 64;
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      if (!(p.dbg & 2)) {
+#pragma unroll
+        for (int kk = 0; kk < 18; ++kk) {
+          const int tap = kk >> 1, r = tap / 3, s_ = tap - r * 3;
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(pt + e[s_][kk & 1] + r * rowstep);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][0], af, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][1], af, acc[1], 0, 0, 0);
+        }
+      }
+      if (p.dbg & 1) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); continue; }
+      // epilogue: acc[nt][rr] = out[pixel li][channel 32*wn + 8*g + 4*nt + rr] -> statistics, packed bf16, ONE 16-byte store
+      typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+      u32x4 o;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { const float v = acc[nt][rr]; ssum[4 * nt + rr] += v; ssq[4 * nt + rr] += v * v; }
+        o[2 * nt] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){acc[nt][0], acc[nt][1]}, bf16x2_t));
+        o[2 * nt + 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){acc[nt][2], acc[nt][3]}, bf16x2_t));
+      }
+      *reinterpret_cast<u32x4*>(p.out + (((size_t)b * p.H + oh0 + orow) * p.W + ow) * CH + wn * 32 + 8 * g) = o;
+    }
+    // next patch landed.  vmcnt retires in issue order and this wave issued its DMA pieces BEFORE its output stores: with at
+    // least 4 stores behind them, "at most 4 outstanding" already proves the pieces are in LDS -- the stores keep draining
+    // under the next block's MFMAs instead of being waited for here.
+    if (tiles_pw >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (p.stats) {
+    // fold the 16 pixels (lanes li) of each channel group, then the 4 m-waves through LDS, in a fixed order
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { ssum[j] += __shfl_xor(ssum[j], o, 64); ssq[j] += __shfl_xor(ssq[j], o, 64); }
+    if (li == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[(wm * 64 + wn * 32 + 8 * g + j) * 2] = ssum[j];
+        red[(wm * 64 + wn * 32 + 8 * g + j) * 2 + 1] = ssq[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
+      p.stats[((size_t)blockIdx.x * 2) * 64 + tid] = s;
+      p.stats[((size_t)blockIdx.x * 2 + 1) * 64 + tid] = q;
     }
   }
 }
@@ -307,7 +457,7 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
   if (!x || !w || !out || grid <= 0) return VQA_EARG;
   C64Params p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
-  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.B = B; p.H = H; p.W = W;
+  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.B = B; p.H = H; p.W = W; p.dbg = 0;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb;
@@ -315,6 +465,32 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
   static size_t attr = 0;
   if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
   hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), shm, st, p);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+// persistent grid of the 8-wave LDS-DMA patch kernel (= rows of its statistics slab), 0 when the shape is unsupported
+int vqa_conv3x3_c64p_blocks(int B, int H, int W) {
+  if (H % RBP || W % 8 || W > 126 || B <= 0) return 0;
+  const size_t shm = (size_t)2 * (RBP + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4;
+  if (shm > 160 * 1024) return 0;
+  const int nb = B * (H / RBP);
+  return nb < 256 ? nb : 256;
+}
+// forward / addend-free data gradient of the 64 -> 64 channel 3x3 conv with the 8-wave LDS-DMA patch kernel (no epilogue inputs)
+int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, hipStream_t st) {
+  const int grid = vqa_conv3x3_c64p_blocks(B, H, W);
+  if (!x || !w || !out || grid <= 0) return VQA_EARG;
+  C64Params p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats; p.addend = nullptr; p.addmask = nullptr;
+  p.B = B; p.H = H; p.W = W;
+  static const int dbg_env = getenv("VQA_C64P_DBG") ? atoi(getenv("VQA_C64P_DBG")) : 0;
+  p.dbg = dbg_env;
+  const size_t xb = (size_t)B * H * W * CH * 2;
+  if (xb >= 0x7fffffffull) return VQA_EARG;
+  p.x_bytes = (unsigned)xb;
+  const size_t shm = (size_t)2 * (RBP + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4;
+  static size_t attr = 0;
+  if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
+  hipLaunchKernelGGL(conv3x3_c64p_kernel, dim3(grid), dim3(512), shm, st, p);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // dw [64][576] fp32 (+=).  ws: scratch of >= vqa_conv3x3_c64_blocks(B,H,W) * 64*576 floats for the deterministic two-pass

@@ -90,6 +90,25 @@ def conv3x3_c64(x, w, B, H, W, *, want_stats=False, addend=None, addmask=None):
     return out, stats, nb
 
 
+def c64p_blocks(B, H, W) -> int:
+    return L.count("vqa_conv3x3_c64p_blocks", B, H, W)
+
+
+def conv3x3_c64p(x, w, B, H, W, *, want_stats=False):
+    """bf16 3x3/1 conv, 64->64 channels, 8-wave LDS-DMA patch kernel (no epilogue inputs).  Returns (out, stats slab | None, blocks)."""
+    nb = c64p_blocks(B, H, W)
+    out = torch.empty((B * H * W, 64), device=x.device, dtype=torch.bfloat16)
+    stats = torch.empty((nb, 2, 64), device=x.device, dtype=torch.float32) if want_stats else None
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_conv3x3_c64p", ptr(x), ptr(w), ptr(out), ptr(stats), B, H, W)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("conv3x3_c64p_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
+    return out, stats, nb
+
+
 def wgrad3x3_c64(x, dy, dw, B, H, W):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
