@@ -122,8 +122,10 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
 /* ---- SpatialAttention.forward (models/attention_modules.py:223-243) and its backward ----------------------------- */
 int vqa_spatial_fwd(int dtype, const void* x, const float* w /* (1,2,7,7) */, float* pooled2, int* argmax, float* amap,
                     void* out, int B, int H, int W, int C, hipStream_t stream);
+long long vqa_spatial_bwd_scratch(int B, int H, int W);   /* floats of `scratch` below (3*B*H*W + the conv-weight partial sums) */
 int vqa_spatial_bwd(int dtype, const void* dout, const void* x, const float* w, const float* pooled2, const int* argmax,
-                    const float* amap, float* scratch /* 3*B*H*W */, void* dx, float* dw, int B, int H, int W, int C, hipStream_t stream);
+                    const float* amap, float* scratch /* vqa_spatial_bwd_scratch() floats */, void* dx, float* dw, int B, int H, int W, int C,
+                    hipStream_t stream);
 int vqa_nhwc_to_nchw(int dtype, const void* in, float* out, int B, int HW, int C, hipStream_t stream);   /* aux['image_features'] */
 int vqa_nchw_to_nhwc(int dtype, const float* in, void* out, int B, int HW, int C, hipStream_t stream);
 
@@ -136,9 +138,14 @@ int vqa_embed_bwd(int dtype, const long long* ids, const void* dout, float* demb
 /* nn.LayerNorm(eps 1e-5) (+dropout, + addrow[row % period]: ImageFeatureProjector, models/fusion.py:98-112) */
 int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* mean_rstd, int rows, int D,
                       float eps, float p, unsigned long long seed, const float* addrow, int period, hipStream_t stream);
+/* Fixed-order reductions.  The entries below that reduce over workgroups take `ws` (uninitialised float scratch, sized by the
+ * matching *_ws query): every workgroup stores its partial sums to its own row and a second launch issued by the same entry
+ * folds the rows in index order (bit-reproducible run to run).  With ws == NULL they fall back to float atomics (same value up
+ * to rounding order). */
+long long vqa_layernorm_bwd_ws(int dtype, int rows, int D, int period /* 0 when dadd == NULL */);
 int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* gamma, const float* mean_rstd, const void* addend,
                       void* dx, float* dgamma, float* dbeta, int rows, int D, float p, unsigned long long seed, float* dadd,
-                      int period, hipStream_t stream);
+                      int period, float* ws, hipStream_t stream);
 /* softmax(QK^T/sqrt(hd) [keys with kmask==0 -> -inf]) (dropout) V, one wave per (batch, head)
  * (models/text_encoder.py:237-258, models/cross_attention.py:176-198); probs = softmax before dropout [B][H][Lq][Lk] */
 int vqa_attention_fwd(int dtype, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const float* kmask,
@@ -166,13 +173,14 @@ int vqa_gate_fwd(int dtype, const void* z, const void* cat, void* fused, int B, 
 int vqa_gate_bwd(int dtype, const void* dfused, const void* z, const void* cat, void* dz, void* dcat, int B, int D, hipStream_t stream);
 int vqa_add(int dtype, const void* a, const void* b, void* out, long long n, hipStream_t stream);
 /* gradient at the pre-activation of linear(+bias)(+ReLU)(+dropout); dbias += column sums */
+long long vqa_bias_act_bwd_ws(int dtype, int M, int N);
 int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, float* dbias, int M, int N, float p,
-                     unsigned long long seed, hipStream_t stream);
+                     unsigned long long seed, float* ws, hipStream_t stream);
 /* nn.CrossEntropyLoss() mean (training/train.py:120): loss += mean NLL, dlogits = (softmax-onehot)*gscale/B.
    err (device int, may be NULL): += number of rows whose target is outside [0, N) -- the reference raises there; such rows are
    never read out of bounds, they add NaN to the loss and get a NaN gradient row. */
 int vqa_cross_entropy(int dtype, const void* logits, const long long* targets, float* loss, void* dlogits, float* logits_f32,
-                      int B, int N, float gscale, int* err, hipStream_t stream);
+                      int B, int N, float gscale, int* err, float* ws /* B floats, or NULL: float atomics on *loss */, hipStream_t stream);
 int vqa_convert(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
 /* clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (training/train.py:204-208,127-132) */
 int vqa_sumsq(const float* g, long long n, float* out /* >= 2049 floats: [0] result (bit-reproducible), rest scratch */, hipStream_t stream);

@@ -12,7 +12,7 @@ from _pkg import REPO, sub
 def _header_symbols():
     txt = open(os.path.join(REPO, "include", "vqa_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(vqa_\w+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(?:int|long long)\s+(vqa_\w+)\s*\(", txt)))
 
 
 def test_header_declares_the_bound_symbols():
@@ -33,7 +33,7 @@ def test_header_arity_matches_ctypes_table():
     L = sub("_lib")
     txt = open(os.path.join(REPO, "include", "vqa_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    for m in re.finditer(r"\bint\s+(vqa_\w+)\s*\((.*?)\)\s*;", txt, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long long)\s+(vqa_\w+)\s*\((.*?)\)\s*;", txt, flags=re.S):
         name, args = m.group(1), m.group(2)
         n = len([a for a in args.split(",") if a.strip()])
         assert n == len(L.SIGNATURES[name]), (name, n, len(L.SIGNATURES[name]))

@@ -66,7 +66,7 @@ def _worker(rank, world, port, q):
     logits, _, tape = eng.forward(shard[0], shard[1], shard[2].float(), True, False, need_tape=True)
     dl = torch.empty_like(logits)
     loss = torch.zeros(1, device="cuda")
-    P._lib.call("vqa_cross_entropy", 0, logits.data_ptr(), shard[3].data_ptr(), loss.data_ptr(), dl.data_ptr(), None, 2, 40, 1.0, None)
+    P._lib.call("vqa_cross_entropy", 0, logits.data_ptr(), shard[3].data_ptr(), loss.data_ptr(), dl.data_ptr(), None, 2, 40, 1.0, None, None)
     eng.backward(tape, dl, G2)
     torch.cuda.synchronize()
     ref = G2.cpu()

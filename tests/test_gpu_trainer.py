@@ -111,7 +111,7 @@ def test_cross_entropy_kernel_matches_torch(dtype):
         lf = torch.empty(B, N, device=DEV)
         err = torch.zeros(1, device=DEV, dtype=torch.int32)
         L.call("vqa_cross_entropy", L.dt(dtype), ld.data_ptr(), td.data_ptr(), loss.data_ptr(), dl.data_ptr(), lf.data_ptr(), B, N, 1.0,
-               err.data_ptr())
+               err.data_ptr(), None)
         torch.cuda.synchronize()
         assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
         tol = 1e-6 if dtype == torch.float32 else 4e-3 * float(ref_in.grad.abs().max())
@@ -130,7 +130,7 @@ def test_cross_entropy_rejects_out_of_range_targets():
     loss = torch.zeros(1, device=DEV)
     dl = torch.empty(B, N, device=DEV)
     err = torch.zeros(1, device=DEV, dtype=torch.int32)
-    L.call("vqa_cross_entropy", 0, logits.data_ptr(), tgt.data_ptr(), loss.data_ptr(), dl.data_ptr(), None, B, N, 1.0, err.data_ptr())
+    L.call("vqa_cross_entropy", 0, logits.data_ptr(), tgt.data_ptr(), loss.data_ptr(), dl.data_ptr(), None, B, N, 1.0, err.data_ptr(), None)
     torch.cuda.synchronize()
     assert int(err.item()) == 3
     assert torch.isnan(loss).all()

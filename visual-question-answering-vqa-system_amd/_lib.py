@@ -52,13 +52,15 @@ SIGNATURES = {
     "vqa_se_fwd": [I, P, P, P, P, P, P, P, I, I, I, I, P],
     "vqa_se_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "vqa_spatial_fwd": [I, P, P, P, P, P, P, I, I, I, I, P],
+    "vqa_spatial_bwd_scratch": [I, I, I],
     "vqa_spatial_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "vqa_nhwc_to_nchw": [I, P, P, I, I, I, P],
     "vqa_nchw_to_nhwc": [I, P, P, I, I, I, P],
     "vqa_embed_fwd": [I, P, P, P, P, I, I, I, I, F, F, ULL, P],
     "vqa_embed_bwd": [I, P, P, P, I, I, I, F, F, ULL, P],
     "vqa_layernorm_fwd": [I, P, P, P, P, P, I, I, F, F, ULL, P, I, P],
-    "vqa_layernorm_bwd": [I, P, P, P, P, P, P, P, P, I, I, F, ULL, P, I, P],
+    "vqa_layernorm_bwd_ws": [I, I, I, I],
+    "vqa_layernorm_bwd": [I, P, P, P, P, P, P, P, P, I, I, F, ULL, P, I, P, P],
     "vqa_attention_fwd": [I, P, P, P, I, I, I, P, P, P, I, I, I, I, I, I, F, ULL, P],
     "vqa_attention_fwd_mfma": [P, P, P, I, I, I, P, P, P, I, I, I, I, I, I, F, ULL, P],
     "vqa_attention_bwd": [I, P, I, P, P, P, I, I, I, P, P, P, P, I, I, I, I, I, I, I, I, F, ULL, P],
@@ -69,15 +71,17 @@ SIGNATURES = {
     "vqa_gate_fwd": [I, P, P, P, I, I, P],
     "vqa_gate_bwd": [I, P, P, P, P, P, I, I, P],
     "vqa_add": [I, P, P, P, LL, P],
-    "vqa_bias_act_bwd": [I, P, P, P, P, I, I, F, ULL, P],
-    "vqa_cross_entropy": [I, P, P, P, P, P, I, I, F, P, P],
+    "vqa_bias_act_bwd_ws": [I, I, I],
+    "vqa_bias_act_bwd": [I, P, P, P, P, I, I, F, ULL, P, P],
+    "vqa_cross_entropy": [I, P, P, P, P, P, I, I, F, P, P, P],
     "vqa_convert": [I, I, P, P, LL, P],
     "vqa_sumsq": [P, LL, P, P],
     "vqa_image_normalize": [P, P, P, I, I, I, F, F, F, F, F, F, P],
     "vqa_pack_tokens": [P, P, P, P, I, I, I, I, I, I, P],
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P],
 }
-_NO_STATUS = {"vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
+_RET_LL = {"vqa_spatial_bwd_scratch", "vqa_layernorm_bwd_ws", "vqa_bias_act_bwd_ws"}                       # return a size (long long)
+_NO_STATUS = _RET_LL | {"vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
 
 _lib = None
 
@@ -92,7 +96,7 @@ def lib() -> C.CDLL:
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = I
+            fn.restype = LL if name in _RET_LL else I
         _lib = L
     return _lib
 

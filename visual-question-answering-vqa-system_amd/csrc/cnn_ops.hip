@@ -503,21 +503,33 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
 }
 
 // dw2[c][j] += sum_b dz2[b][c]*hidden[b][j] ; dw1[j][c] += sum_b dh[b][j]*pooled[b][c]
-// One thread per (j, c) pair with c fastest (coalesced dz2 / pooled rows, broadcast hidden / dh); the batch is sliced over grid.y.
+// A workgroup owns 8 consecutive (j, c) pairs (c fastest) and splits the batch over 32 thread slices; the slices are folded in LDS
+// in slice order, so every weight has ONE writer and a fixed summation order (bit-reproducible, no atomics, no scratch).
 __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ dz2, const float* __restrict__ hidden, const float* __restrict__ dh,
                                 const float* __restrict__ pooled, float* dw1, float* dw2, int B, int C, int Cr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C * Cr) return;
-  const int j = i / C, c = i - j * C;
-  const int per = (B + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const int pr = threadIdx.x & 7, q = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + pr;
+  const bool live = i < C * Cr;
+  const int j = live ? i / C : 0, c = live ? i - j * C : 0;
   float t2 = 0.f, t1 = 0.f;
+  if (live) {
 #pragma unroll 4
-  for (int b = b0; b < b1; ++b) {
-    t2 += dz2[(size_t)b * C + c] * hidden[(size_t)b * Cr + j];
-    t1 += dh[(size_t)b * Cr + j] * pooled[(size_t)b * C + c];
+    for (int b = q; b < B; b += 32) {
+      t2 += dz2[(size_t)b * C + c] * hidden[(size_t)b * Cr + j];
+      t1 += dh[(size_t)b * Cr + j] * pooled[(size_t)b * C + c];
+    }
   }
-  atomicAdd(dw2 + (size_t)c * Cr + j, t2);
-  atomicAdd(dw1 + (size_t)j * C + c, t1);
+  __shared__ float sh[2][32][8];
+  sh[0][q][pr] = t2; sh[1][q][pr] = t1;
+  __syncthreads();
+  if (threadIdx.x < 16 && blockIdx.x * 8 + (threadIdx.x & 7) < C * Cr) {
+    const int which = threadIdx.x >> 3, pp = threadIdx.x & 7;
+    const int ii = blockIdx.x * 8 + pp, jj = ii / C, cc = ii - jj * C;
+    float t = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < 32; ++s_) t += sh[which][s_][pp];
+    if (which == 0) dw2[(size_t)cc * Cr + jj] += t; else dw1[(size_t)jj * C + cc] += t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -615,8 +627,10 @@ __global__ void spatial_bwd_apply_kernel(const T* __restrict__ dout, const float
   }
 }
 
-// dw[ch][r][s] += sum_{b,h,w} dpre[b][h][w] * pooled2[b][h+r-3][w+s-3][ch] ; one block per (ch,r,s)
-__global__ __launch_bounds__(256) void spatial_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ pooled2, float* dw, int B, int H, int W) {
+// part[y][ch][r][s] = sum over slice y of the pixels of dpre[b][h][w] * pooled2[b][h+r-3][w+s-3][ch] ; one block per ((ch,r,s), slice);
+// spatial_wgrad_finish_kernel folds the slices in slice order into dw (one writer per weight: bit-reproducible, no atomics).
+constexpr int SPATIAL_WG_SLICES = 16;
+__global__ __launch_bounds__(256) void spatial_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ pooled2, float* __restrict__ part, int B, int H, int W) {
   const int o = blockIdx.x, ch = o / 49, r = (o % 49) / 7, s = o % 7;
   float t = 0.f;
   const size_t n = (size_t)B * H * W;
@@ -630,7 +644,15 @@ __global__ __launch_bounds__(256) void spatial_wgrad_kernel(const float* __restr
   t = wave_sum(t);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(dw + o, sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) part[blockIdx.y * 98 + o] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void spatial_wgrad_finish_kernel(const float* __restrict__ part, float* dw) {
+  const int o = threadIdx.x;
+  if (o >= 98) return;
+  float t = 0.f;
+#pragma unroll
+  for (int y = 0; y < SPATIAL_WG_SLICES; ++y) t += part[y * 98 + o];
+  dw[o] += t;
 }
 
 // NHWC(T) <-> NCHW(fp32) boundary conversions (aux['image_features'] is NCHW fp32 at the API boundary)
@@ -775,7 +797,7 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   if (npix >= (1ull << 28)) return VQA_EARG;
   DT(hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const float*)dout, scale, dpool, (float*)dx, (unsigned)npix, HW, C, magic40(HW), mask_out ? (const float*)x : nullptr),
      hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const bf16_t*)dout, scale, dpool, (bf16_t*)dx, (unsigned)npix, HW, C, magic40(HW), mask_out ? (const bf16_t*)x : nullptr));
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 255) / 256, B >= 64 ? 8 : 1), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 7) / 8), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 
@@ -793,12 +815,14 @@ int vqa_spatial_fwd(int dtype, const void* x, const float* w, float* pooled2, in
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // scratch: dpre[B*H*W] | dpool2[B*H*W*2] floats
+// floats of the `scratch` argument of vqa_spatial_bwd: dpre [npix] + dpool2 [npix][2] + the conv-weight partial sums [16][98]
+long long vqa_spatial_bwd_scratch(int B, int H, int W) { return 3ll * B * H * W + SPATIAL_WG_SLICES * 98; }
 int vqa_spatial_bwd(int dtype, const void* dout, const void* x, const float* w, const float* pooled2, const int* amax, const float* amap,
                     float* scratch, void* dx, float* dw, int B, int H, int W, int C, hipStream_t st) {
   const int VEC = dtype ? 8 : 4;
   if (C % VEC) return VQA_EARG;
   const size_t npix = (size_t)B * H * W;
-  float* dpre = scratch; float* dpool2 = dpre + npix;
+  float* dpre = scratch; float* dpool2 = dpre + npix; float* wpart = dpool2 + 2 * npix;
   const int pg = (int)((npix + 3) / 4 > 8192 ? 8192 : (npix + 3) / 4);
   DT(hipLaunchKernelGGL(spatial_bwd_reduce_kernel<float>, dim3(pg), dim3(256), 0, st, (const float*)dout, (const float*)x, amap, dpre, npix, C),
      hipLaunchKernelGGL(spatial_bwd_reduce_kernel<bf16_t>, dim3(pg), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, amap, dpre, npix, C));
@@ -806,7 +830,8 @@ int vqa_spatial_bwd(int dtype, const void* dout, const void* x, const float* w, 
   if (npix >= (1ull << 28) || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
   DT(hipLaunchKernelGGL(spatial_bwd_apply_kernel<float>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const float*)dout, amap, dpool2, amax, (float*)dx, (unsigned)npix, C),
      hipLaunchKernelGGL(spatial_bwd_apply_kernel<bf16_t>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const bf16_t*)dout, amap, dpool2, amax, (bf16_t*)dx, (unsigned)npix, C));
-  hipLaunchKernelGGL(spatial_wgrad_kernel, dim3(98, 16), dim3(256), 0, st, dpre, pooled2, dw, B, H, W);
+  hipLaunchKernelGGL(spatial_wgrad_kernel, dim3(98, SPATIAL_WG_SLICES), dim3(256), 0, st, dpre, pooled2, wpart, B, H, W);
+  hipLaunchKernelGGL(spatial_wgrad_finish_kernel, dim3(1), dim3(128), 0, st, wpart, dw);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 

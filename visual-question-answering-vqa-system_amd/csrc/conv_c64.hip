@@ -246,28 +246,50 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
   for (; blk < nblocks; blk += gridDim.x, buf ^= 1) {
     const int nxt = blk + gridDim.x;
     if (nxt < nblocks && !(p.dbg & 4)) issue_patch(nxt, buf ^ 1);   // the other buffer: every wave finished reading it at the last barrier
-    const bf16_t* pt = buf ? patch1 : patch0;
+    const unsigned pbase = lds0 + (unsigned)buf * (unsigned)(patch_elems * 2);
     const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBP;
-    for (int mt = wm; mt < mtiles; mt += 4) {
-      const int px = mt * 16 + li, orow = (int)(((float)px + 0.5f) * inv_w), ow = px - orow * p.W;
-      int e[3][2];
+    // LDS byte addresses of a tile's six (tap column, channel half) fragments in patch row 0
+    auto tile_addr = [&](int mt, unsigned (&ea)[3][2], int& orow, int& ow) {
+      const int px = mt * 16 + li;
+      orow = (int)(((float)px + 0.5f) * inv_w);
+      ow = px - orow * p.W;
 #pragma unroll
       for (int s_ = 0; s_ < 3; ++s_) {
-        const int col = ow + s_, cb = (orow * PWc + col) * 64;
-        e[s_][0] = cb + ((g ^ (col & 7)) << 3);
-        e[s_][1] = cb + (((4 + g) ^ (col & 7)) << 3);
+        const int col = ow + s_, cb = (orow * PWc + col) * 128;
+        ea[s_][0] = pbase + (unsigned)(cb + ((g ^ (col & 7)) << 4));
+        ea[s_][1] = pbase + (unsigned)(cb + (((4 + g) ^ (col & 7)) << 4));
       }
-      const int rowstep = PWc * 64;
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      if (!(p.dbg & 2)) {
+    };
+    const unsigned rowstep = (unsigned)(PWc * 128);
+    // The activation fragments go through a ring of PF registers filled by hand-issued ds_read_b128 with counted lgkmcnt waits
+    // (LDS returns in order): PF-1 reads stay in flight across the MFMAs and across tile boundaries.  Left to itself the compiler
+    // keeps one read ahead, which at two waves per SIMD exposes the LDS latency on every pair of MFMAs.
+    constexpr int PF = 6;                                       // divides 18: slot = kk % PF for this tile and the next
+    bf16x8 ring[PF];
+    unsigned ec[3][2], en[3][2];
+    int orow, ow, orow_n, ow_n;
+    tile_addr(wm, ec, orow, ow);
 #pragma unroll
-        for (int kk = 0; kk < 18; ++kk) {
-          const int tap = kk >> 1, r = tap / 3, s_ = tap - r * 3;
-          const bf16x8 af = *reinterpret_cast<const bf16x8*>(pt + e[s_][kk & 1] + r * rowstep);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][0], af, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][1], af, acc[1], 0, 0, 0);
-        }
+    for (int kk = 0; kk < PF; ++kk) {
+      const int tap = kk >> 1, r = tap / 3, s_ = tap - r * 3;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(ring[kk]) : "v"(ec[s_][kk & 1] + (unsigned)r * rowstep));
+    }
+    for (int mt = wm; mt < mtiles; mt += 4) {
+      tile_addr(mt + 4 < mtiles ? mt + 4 : mt, en, orow_n, ow_n);   // the block's last tile re-reads itself (drained at the barrier)
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kk = 0; kk < 18; ++kk) {
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[kk % PF]) : "n"(PF - 1));
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][0], ring[kk % PF], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][1], ring[kk % PF], acc[1], 0, 0, 0);
+        const int kn = (kk + PF) % 18, tap = kn >> 1, r = tap / 3, s_ = tap - r * 3;
+        const unsigned ad = (kk + PF < 18 ? ec[s_][kn & 1] : en[s_][kn & 1]) + (unsigned)r * rowstep;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ring[kk % PF]) : "v"(ad));
       }
+      const int orow_c = orow, ow_c = ow;
+      orow = orow_n; ow = ow_n;
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) { ec[s_][0] = en[s_][0]; ec[s_][1] = en[s_][1]; }
       if (p.dbg & 1) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); continue; }
       // epilogue: acc[nt][rr] = out[pixel li][channel 32*wn + 8*g + 4*nt + rr] -> statistics, packed bf16, ONE 16-byte store
       typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
         o[2 * nt] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){acc[nt][0], acc[nt][1]}, bf16x2_t));
         o[2 * nt + 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){acc[nt][2], acc[nt][3]}, bf16x2_t));
       }
-      *reinterpret_cast<u32x4*>(p.out + (((size_t)b * p.H + oh0 + orow) * p.W + ow) * CH + wn * 32 + 8 * g) = o;
+      *reinterpret_cast<u32x4*>(p.out + (((size_t)b * p.H + oh0 + orow_c) * p.W + ow_c) * CH + wn * 32 + 8 * g) = o;
     }
     // next patch landed.  vmcnt retires in issue order and this wave issued its DMA pieces BEFORE its output stores: with at
     // least 4 stores behind them, "at most 4 outstanding" already proves the pieces are in LDS -- the stores keep draining

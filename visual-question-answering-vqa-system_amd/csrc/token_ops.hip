@@ -22,17 +22,106 @@ __global__ void embed_fwd_kernel(const long long* __restrict__ ids, const float*
   if (p > 0.f) v = drop_keep32(drop_key(seed), (uint32_t)(i), p) ? v / (1.f - p) : 0.f;
   out[i] = from_f<T>(v);
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// Fixed-order cross-workgroup reductions.  A kernel whose workgroups each hold a partial vector (bias / LayerNorm gamma, beta /
+// position-embedding gradients, loss terms) stores it to its own row of a caller-provided scratch slab; fold_rows_kernel, launched
+// right behind it on the same stream by the same C entry, sums the rows IN INDEX ORDER and performs the single += on the
+// destination.  The result does not depend on the order the workgroups ran in (float atomics do): bit-reproducible gradients.
+// (A same-kernel "last workgroup finishes" variant was measured first: its agent-scope release/acquire fences write back and
+// invalidate the XCD's L2 once per workgroup, +50 us per LayerNorm backward; the kernel boundary gives the same visibility for
+// one ~2 us launch.)
+// block (64, 16): 64 columns x 16 row groups; a group sums a contiguous chunk of rows in index order with 16 loads in flight,
+// the 16 group sums are folded in group order.  Columns [0, n0) go to dst0, [n0, ncols) to dst1.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void fold_rows_kernel(const float* __restrict__ part, int nrows, size_t stride, int ncols,
+                                                         float* dst0, int n0, float* dst1) {
+  const int c = blockIdx.x * 64 + threadIdx.x, rg = threadIdx.y;
+  const int per = (nrows + 15) / 16, r0 = rg * per, r1 = min(nrows, r0 + per);
+  float t = 0.f;
+  if (c < ncols) {
+    int r = r0;
+    for (; r + 16 <= r1; r += 16) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = part[(size_t)(r + i) * stride + c];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += v[i];
+    }
+    for (; r < r1; ++r) t += part[(size_t)r * stride + c];
+  }
+  __shared__ float sh[16][64];
+  sh[rg][threadIdx.x] = t;
+  __syncthreads();
+  if (rg == 0 && c < ncols) {
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) a += sh[g][threadIdx.x];
+    if (c < n0) dst0[c] += a; else dst1[c - n0] += a;
+  }
+}
+static inline void launch_fold(const float* part, int nrows, size_t stride, int ncols, float* dst0, int n0, float* dst1, hipStream_t st) {
+  hipLaunchKernelGGL(fold_rows_kernel, dim3((ncols + 63) / 64), dim3(64, 16), 0, st, part, nrows, stride, ncols, dst0, n0, dst1);
+}
+
+// Gradient of the embedding table WITHOUT atomics: a workgroup owns 16 consecutive table rows, walks the id list in row order
+// (1024 ids per pass, hits compacted in order through LDS) and adds the matching rows of dout to LDS accumulators in that order
+// -> bit-reproducible, one writer per table element.  (The id list is rows*8 bytes, L2-resident, read V/16 times; the reference's
+// nn.Embedding backward is a deterministic CPU scatter-add.)
+constexpr int EMB_VB = 16;
 template <typename T>
-__global__ void embed_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ dout, float* demb,
-                                 int rows, int D, int V, float scale, float p, uint64_t seed) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)rows * D) return;
-  const int d = (int)(i % D), row = (int)(i / D);
-  const long long id = ids[row];
-  if (id <= 0 || id >= V) return;                       // padding_idx = 0 receives no gradient
-  float g = to_f<T>(dout[i]) * scale;
-  if (p > 0.f) g = drop_keep32(drop_key(seed), (uint32_t)(i), p) ? g / (1.f - p) : 0.f;
-  atomicAdd(demb + (size_t)id * D + d, g);
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ dout, float* demb,
+                                                        int rows, int D, int V, float scale, float p, uint64_t seed) {
+  extern __shared__ float eacc[];                             // [EMB_VB][D]
+  __shared__ int list[1024];                                  // (row << 4) | (id - v0), in row order
+  __shared__ int wcnt[4];
+  const long long v0 = (long long)blockIdx.x * EMB_VB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < EMB_VB * D; i += 256) eacc[i] = 0.f;
+  const uint32_t dkey = drop_key(seed);
+  const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  bool any = false;
+  for (int base = 0; base < rows; base += 1024) {
+    // thread t owns rows base + 4t .. base + 4t + 3 (row order == thread order, then k)
+    int hit[4];
+    int nh = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = base + threadIdx.x * 4 + k;
+      const long long id = r < rows ? ids[r] : -1;
+      const bool h = id >= v0 && id < v0 + EMB_VB && id > 0 && id < V;       // padding_idx = 0 receives no gradient
+      hit[k] = h ? (int)(id - v0) : -1;
+      nh += h;
+    }
+    // exclusive prefix of nh over the 256 threads: wave scan + wave totals through LDS
+    int incl = nh;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    if (lane == 63) wcnt[wave] = incl;
+    __syncthreads();
+    int off = incl - nh, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wave) off += wcnt[w]; total += wcnt[w]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (hit[k] >= 0) list[off++] = ((base + threadIdx.x * 4 + k) << 4) | hit[k];
+    __syncthreads();
+    for (int i = 0; i < total; ++i) {
+      const int e = list[i], row = e >> 4, slot = e & 15;
+      for (int d = threadIdx.x; d < D; d += 256) {
+        const size_t o = (size_t)row * D + d;
+        float g = to_f<T>(dout[o]) * scale;
+        if (p > 0.f) g = drop_keep32(dkey, (uint32_t)o, p) ? g * ks : 0.f;
+        eacc[slot * D + d] += g;                             // column d is only ever touched by this thread
+      }
+    }
+    any |= total > 0;
+    __syncthreads();
+  }
+  if (!any) return;
+  for (int i = threadIdx.x; i < EMB_VB * D; i += 256) {
+    const long long v = v0 + i / D;
+    if (v > 0 && v < V && eacc[i] != 0.f) demb[(size_t)v * D + (i % D)] += eacc[i];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -111,7 +200,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ stats, const T* __restrict__ addend, T* __restrict__ dx,
                                                             float* dgamma, float* dbeta, int rows, int D, float p, uint64_t seed,
-                                                            float* dadd, int period) {
+                                                            float* dadd, int period, float* part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
   float ag[8], ab[8];
@@ -153,30 +242,48 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
   for (int t = 0; t < 8; ++t) { sh[0][wave][lane + 64 * t] = ag[t]; sh[1][wave][lane + 64 * t] = ab[t]; }
   __syncthreads();
+  if (!part) {                                                // no scratch: float atomics (order-dependent rounding)
+    for (int c = threadIdx.x; c < D; c += 256) {
+      atomicAdd(dgamma + c, sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c]);
+      atomicAdd(dbeta + c, sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c]);
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < D; c += 256) {
-    atomicAdd(dgamma + c, sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c]);
-    atomicAdd(dbeta + c, sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c]);
+    part[((size_t)blockIdx.x * 2) * D + c] = sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c];
+    part[((size_t)blockIdx.x * 2 + 1) * D + c] = sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c];
   }
 }
 
 // out[n] += sum_b x[b][n] for x [B][N] (N % Vec16<T>::N == 0): the gradient of a row-periodic addend (position embedding),
 // one 16-byte column group per thread, grid.y slices of the batch, one atomic per column per slice.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_rows_kernel(const T* __restrict__ x, float* out, int B, size_t N) {
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const T* __restrict__ x, float* out, int B, size_t N, float* part) {
   constexpr int VEC = Vec16<T>::N;
   const size_t n0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;
-  if (n0 >= N) return;
+  const bool live = n0 < N;
   float acc[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (live) {
 #pragma unroll 4
-  for (int b = blockIdx.y; b < B; b += gridDim.y) {
-    const Vec16<T> t = ldg16(x + (size_t)b * N + n0);
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+      const Vec16<T> t = ldg16(x + (size_t)b * N + n0);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] += t.get(j);
+      for (int j = 0; j < VEC; ++j) acc[j] += t.get(j);
+    }
   }
+  if (!part) {                                                // no scratch: float atomics (order-dependent rounding)
+    if (live) {
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) atomicAdd(out + n0 + j, acc[j]);
+      for (int j = 0; j < VEC; ++j) atomicAdd(out + n0 + j, acc[j]);
+    }
+    return;
+  }
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) part[(size_t)blockIdx.y * N + n0 + j] = acc[j];
+  }
 }
 
 // bf16, D % 8 == 0, D <= 512: lane owns channels [8*lane, 8*lane+8) -> one 16-byte load per operand per row, gamma and the
@@ -184,7 +291,8 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const T* __restrict__ 
 __global__ __launch_bounds__(512) void layernorm_bwd_bf16v_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
                                                                   const float* __restrict__ gamma, const float* __restrict__ stats,
                                                                   const bf16_t* __restrict__ addend, bf16_t* __restrict__ dx, float* dgamma,
-                                                                  float* dbeta, int rows, int D, float p, uint64_t seed, float* dadd, int period) {
+                                                                  float* dbeta, int rows, int D, float p, uint64_t seed, float* dadd, int period,
+                                                                  float* part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wid = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
   const int c0 = lane * 8;
@@ -229,8 +337,8 @@ __global__ __launch_bounds__(512) void layernorm_bwd_bf16v_kernel(const bf16_t* 
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) { a += sh[0][w][c]; b += sh[1][w][c]; }
-    atomicAdd(dgamma + c, a);
-    atomicAdd(dbeta + c, b);
+    if (part) { part[((size_t)blockIdx.x * 2) * D + c] = a; part[((size_t)blockIdx.x * 2 + 1) * D + c] = b; }
+    else { atomicAdd(dgamma + c, a); atomicAdd(dbeta + c, b); }
   }
 }
 
@@ -404,7 +512,8 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
 // dz = dout * [out>0] * dropout-keep-scale ; dbias[n] += column sums of dz
 template <typename T>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ outact, T* __restrict__ dz,
-                                                           float* dbias, int M, int N, int relu_drop, float p, uint64_t seed) {
+                                                           float* dbias, int M, int N, int relu_drop, float p, uint64_t seed,
+                                                           float* part) {
   // block handles a strip of 64 columns x rows_per_block rows; thread (r = tid/64, c = tid%64)
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int rows_per = (M + gridDim.y - 1) / gridDim.y;
@@ -422,8 +531,11 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
   __shared__ float sh[4][64];
   sh[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && c < N && dbias) atomicAdd(dbias + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
   (void)relu_drop;
+  if (!dbias) return;
+  const float tcol = sh[0][threadIdx.x & 63] + sh[1][threadIdx.x & 63] + sh[2][threadIdx.x & 63] + sh[3][threadIdx.x & 63];
+  if (!part) { if (rl == 0 && c < N) atomicAdd(dbias + c, tcol); return; }
+  if (rl == 0 && c < N) part[(size_t)blockIdx.y * N + c] = tcol;
 }
 
 // Vectorised form of bias_act_bwd_kernel for N % 8 == 0 (bf16) / N % 4 == 0 (fp32): a thread owns one 16-byte column group and
@@ -431,7 +543,8 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
 // dbias: per-thread partial sums, folded over the block's row lanes in LDS, one atomic per column per block.
 template <typename T>
 __global__ __launch_bounds__(256) void bias_act_bwd_vec_kernel(const T* __restrict__ dout, const T* __restrict__ outact, T* __restrict__ dz,
-                                                               float* dbias, int M, int N, float p, uint64_t seed, int rows_per) {
+                                                               float* dbias, int M, int N, float p, uint64_t seed, int rows_per,
+                                                               float* part) {
   constexpr int VEC = Vec16<T>::N;
   const int cvs = N / VEC;                                   // column groups per row
   const int gpb = cvs < 256 ? cvs : 256;                     // column groups handled by one block (per blockIdx.x)
@@ -470,38 +583,42 @@ __global__ __launch_bounds__(256) void bias_act_bwd_vec_kernel(const T* __restri
     float t = 0.f;
     for (int r = 0; r < lanes_r; ++r) t += sh[(r * gpb + gq) * VEC + j];
     const int col = (blockIdx.x * gpb + gq) * VEC + j;
-    if (col < N) atomicAdd(dbias + col, t);
+    if (col < N) { if (part) part[(size_t)blockIdx.y * N + col] = t; else atomicAdd(dbias + col, t); }
   }
 }
 
 // cross entropy (mean) forward+backward in one pass: wave per row
 template <typename T>
-__global__ void cross_entropy_kernel(const T* __restrict__ logits, const long long* __restrict__ targets, float* loss, T* __restrict__ dlogits,
-                                     float* __restrict__ logits_f32, int B, int N, float gscale, int* err) {
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const T* __restrict__ logits, const long long* __restrict__ targets, float* loss,
+                                                            T* __restrict__ dlogits, float* __restrict__ logits_f32, int B, int N, float gscale,
+                                                            int* err, float* part) {
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= B) return;
-  const T* lr = logits + (size_t)row * N;
-  float m = -INFINITY;
-  for (int c = lane; c < N; c += 64) m = fmaxf(m, to_f<T>(lr[c]));
-  m = wave_max(m);
-  float s = 0.f;
-  for (int c = lane; c < N; c += 64) s += expf(to_f<T>(lr[c]) - m);
-  s = wave_sum(s);
-  const long long t64 = targets[row];
-  // a target outside [0, N) raises in the reference (nn.CrossEntropyLoss, training/train.py:120): never read out of bounds,
-  // count the row in *err (the host mirror raises from it) and poison its loss term and gradient row with NaN
-  const bool bad = t64 < 0 || t64 >= (long long)N;
-  const int t = bad ? 0 : (int)t64;
-  const float lse = m + logf(s);
-  if (lane == 0) {
-    if (loss) atomicAdd(loss, bad ? __builtin_nanf("") : (lse - to_f<T>(lr[t])) / (float)B);
-    if (bad && err) atomicAdd(err, 1);
-  }
-  for (int c = lane; c < N; c += 64) {
-    const float x = to_f<T>(lr[c]);
-    if (logits_f32) logits_f32[(size_t)row * N + c] = x;
-    if (dlogits) dlogits[(size_t)row * N + c] = from_f<T>(bad ? __builtin_nanf("") : (expf(x - lse) - (c == t ? 1.f : 0.f)) * gscale / (float)B);
+  if (row < B) {
+    const T* lr = logits + (size_t)row * N;
+    float m = -INFINITY;
+    for (int c = lane; c < N; c += 64) m = fmaxf(m, to_f<T>(lr[c]));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < N; c += 64) s += expf(to_f<T>(lr[c]) - m);
+    s = wave_sum(s);
+    const long long t64 = targets[row];
+    // a target outside [0, N) raises in the reference (nn.CrossEntropyLoss, training/train.py:120): never read out of bounds,
+    // count the row in *err (the host mirror raises from it) and poison its loss term and gradient row with NaN
+    const bool bad = t64 < 0 || t64 >= (long long)N;
+    const int t = bad ? 0 : (int)t64;
+    const float lse = m + logf(s);
+    if (lane == 0) {
+      const float term = bad ? __builtin_nanf("") : (lse - to_f<T>(lr[t])) / (float)B;
+      if (part) part[row] = term;
+      else if (loss) atomicAdd(loss, term);
+      if (bad && err) atomicAdd(err, 1);
+    }
+    for (int c = lane; c < N; c += 64) {
+      const float x = to_f<T>(lr[c]);
+      if (logits_f32) logits_f32[(size_t)row * N + c] = x;
+      if (dlogits) dlogits[(size_t)row * N + c] = from_f<T>(bad ? __builtin_nanf("") : (expf(x - lse) - (c == t ? 1.f : 0.f)) * gscale / (float)B);
+    }
   }
 }
 
@@ -576,9 +693,14 @@ int vqa_embed_fwd(int dtype, const long long* ids, const float* emb, const float
 }
 int vqa_embed_bwd(int dtype, const long long* ids, const void* dout, float* demb, int rows, int D, int V, float scale, float p,
                   unsigned long long seed, hipStream_t st) {
-  const size_t n = (size_t)rows * D;
-  DT(hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(g1(n)), dim3(256), 0, st, ids, (const float*)dout, demb, rows, D, V, scale, p, seed),
-     hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(g1(n)), dim3(256), 0, st, ids, (const bf16_t*)dout, demb, rows, D, V, scale, p, seed));
+  if (D > 2048 || rows <= 0 || rows >= (1 << 27) || V <= 0) return VQA_EARG;
+  const size_t shm = (size_t)EMB_VB * D * 4;
+  const dim3 grid((V + EMB_VB - 1) / EMB_VB);
+  static size_t attr_f = 0, attr_b = 0;
+  if (!dtype && shm > 65536 - 4200 && shm > attr_f) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_f = shm; }
+  if (dtype && shm > 65536 - 4200 && shm > attr_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_b = shm; }
+  DT(hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), shm, st, ids, (const float*)dout, demb, rows, D, V, scale, p, seed),
+     hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), shm, st, ids, (const bf16_t*)dout, demb, rows, D, V, scale, p, seed));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* stats, int rows, int D, float eps,
@@ -597,27 +719,52 @@ int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
      hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)out, stats, rows, D, eps, p, seed, addrow, period));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
+// launch geometry of vqa_layernorm_bwd (shared with the scratch-size query)
+struct LnBwdGeom { int nb; bool colsum; unsigned gx, gy; size_t N; };
+static LnBwdGeom ln_bwd_geom(int dtype, int rows, int D, int period) {
+  LnBwdGeom g = {0, false, 0, 0, 0};
+  if (dtype && D % 8 == 0) { g.nb = (rows + 31) / 32; if (g.nb > 256) g.nb = 256; }
+  else g.nb = (rows + 15) / 16 > 2048 ? 2048 : (rows + 15) / 16;
+  if (period > 0 && rows % period == 0 && ((size_t)period * D) % (dtype ? 8 : 4) == 0) {
+    const int Bb = rows / period;
+    g.colsum = true; g.N = (size_t)period * D;
+    g.gx = (unsigned)((g.N / (dtype ? 8 : 4) + 255) / 256); g.gy = Bb < 32 ? Bb : 32;
+  }
+  return g;
+}
+// Floats of the `ws` scratch of vqa_layernorm_bwd (per-workgroup partial rows, see fold_rows_kernel).  period = the addrow period
+// when dadd is requested, else 0.
+long long vqa_layernorm_bwd_ws(int dtype, int rows, int D, int period) {
+  if (D > 512 || rows <= 0) return 0;
+  const LnBwdGeom g = ln_bwd_geom(dtype, rows, D, period);
+  return (long long)g.nb * 2 * D + (g.colsum ? (long long)g.gy * (long long)g.N : 0);
+}
+// ws: scratch of vqa_layernorm_bwd_ws floats -> dgamma / dbeta / dadd are summed in a fixed order (bit-reproducible);
+// nullptr -> float atomics (same values up to rounding order).
 int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* gamma, const float* stats, const void* addend, void* dx,
-                      float* dgamma, float* dbeta, int rows, int D, float p, unsigned long long seed, float* dadd, int period, hipStream_t st) {
+                      float* dgamma, float* dbeta, int rows, int D, float p, unsigned long long seed, float* dadd, int period,
+                      float* ws, hipStream_t st) {
   if (D > 512 || rows <= 0) return VQA_EARG;
-  if (dadd && period > 0 && rows % period == 0 && ((size_t)period * D) % (dtype ? 8 : 4) == 0) {
+  const LnBwdGeom g = ln_bwd_geom(dtype, rows, D, dadd ? period : 0);
+  float* part_ln = ws;
+  float* part_cs = ws ? ws + (size_t)g.nb * 2 * D : nullptr;
+  if (dadd && g.colsum) {
     // position-embedding gradient as its own column-sum pass (one read of dout) instead of rows*D atomics inside the LN kernel
     const int Bb = rows / period;
-    const size_t N = (size_t)period * D, nv = N / (dtype ? 8 : 4);
-    dim3 grid((unsigned)((nv + 255) / 256), Bb < 32 ? Bb : 32);
-    DT(hipLaunchKernelGGL(colsum_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, dadd, Bb, N),
-       hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, dadd, Bb, N));
+    dim3 grid(g.gx, g.gy);
+    DT(hipLaunchKernelGGL(colsum_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, dadd, Bb, g.N, part_cs),
+       hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, dadd, Bb, g.N, part_cs));
+    if (part_cs) launch_fold(part_cs, (int)g.gy, g.N, (int)g.N, dadd, (int)g.N, nullptr, st);
     dadd = nullptr;
   }
   if (dtype && D % 8 == 0) {                               // vectorised bf16 path, >= 4 rows per wave, at most one workgroup per CU
-    int gv = (rows + 31) / 32; if (gv > 256) gv = 256;
-    hipLaunchKernelGGL(layernorm_bwd_bf16v_kernel, dim3(gv), dim3(512), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, stats,
-                       (const bf16_t*)addend, (bf16_t*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period);
-    VQA_LAUNCH_CHECK(); return VQA_OK;
+    hipLaunchKernelGGL(layernorm_bwd_bf16v_kernel, dim3(g.nb), dim3(512), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, stats,
+                       (const bf16_t*)addend, (bf16_t*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period, part_ln);
+  } else {
+    DT(hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(g.nb), dim3(256), 0, st, (const float*)dout, (const float*)x, gamma, stats, (const float*)addend, (float*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period, part_ln),
+       hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(g.nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, stats, (const bf16_t*)addend, (bf16_t*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period, part_ln));
   }
-  const int grid = (rows + 15) / 16 > 2048 ? 2048 : (rows + 15) / 16;
-  DT(hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)x, gamma, stats, (const float*)addend, (float*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period),
-     hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, stats, (const bf16_t*)addend, (bf16_t*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period));
+  if (part_ln) launch_fold(part_ln, g.nb, (size_t)2 * D, 2 * D, dgamma, D, dbeta, st);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_attention_fwd(int dtype, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const float* kmask, float* probs,
@@ -669,31 +816,54 @@ int vqa_add(int dtype, const void* a, const void* b, void* out, long long n, hip
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // outact != null: relu (and dropout folded into out>0); outact == null && p>0: dropout mask regenerated from (seed, index)
-int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, float* dbias, int M, int N, float p, unsigned long long seed, hipStream_t st) {
+struct BiasBwdGeom { bool vec; int gpb, rows_per; dim3 grid; };
+static BiasBwdGeom bias_bwd_geom(int dtype, int M, int N) {
+  BiasBwdGeom g;
   const int VEC = dtype ? 8 : 4;
-  if (N % VEC == 0 && M > 0 && (256 % (N / VEC < 256 ? N / VEC : 256)) == 0) {
+  g.vec = N % VEC == 0 && M > 0 && (256 % (N / VEC < 256 ? N / VEC : 256)) == 0;
+  if (g.vec) {
     const int cvs = N / VEC, gpb = cvs < 256 ? cvs : 256, lanes_r = 256 / gpb;
     int gy = (M + 16 * lanes_r - 1) / (16 * lanes_r);        // ~16 row passes per block; <= 1024 blocks in y
     if (gy > 1024) gy = 1024;
     if (gy < 1) gy = 1;
-    const int rows_per = (M + gy - 1) / gy;
-    dim3 grid((cvs + gpb - 1) / gpb, (M + rows_per - 1) / rows_per);
-    DT(hipLaunchKernelGGL(bias_act_bwd_vec_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)outact, (float*)dz, dbias, M, N, p, seed, rows_per),
-       hipLaunchKernelGGL(bias_act_bwd_vec_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (bf16_t*)dz, dbias, M, N, p, seed, rows_per));
-    VQA_LAUNCH_CHECK(); return VQA_OK;
+    g.gpb = gpb; g.rows_per = (M + gy - 1) / gy;
+    g.grid = dim3((cvs + gpb - 1) / gpb, (M + g.rows_per - 1) / g.rows_per);
+  } else {
+    int gy = (M + 127) / 128; if (gy > 256) gy = 256; if (gy < 1) gy = 1;
+    g.gpb = 0; g.rows_per = 0; g.grid = dim3((N + 63) / 64, gy);
   }
-  int gy = (M + 127) / 128; if (gy > 256) gy = 256; if (gy < 1) gy = 1;
-  dim3 grid((N + 63) / 64, gy);
-  DT(hipLaunchKernelGGL(bias_act_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)outact, (float*)dz, dbias, M, N, 0, p, seed),
-     hipLaunchKernelGGL(bias_act_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (bf16_t*)dz, dbias, M, N, 0, p, seed));
+  return g;
+}
+// Floats of the `ws` scratch of vqa_bias_act_bwd (one partial row of N column sums per workgroup row).
+long long vqa_bias_act_bwd_ws(int dtype, int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  const BiasBwdGeom g = bias_bwd_geom(dtype, M, N);
+  return (long long)g.grid.y * N;
+}
+// ws: vqa_bias_act_bwd_ws floats -> dbias summed in a fixed order (bit-reproducible); nullptr -> float atomics on dbias.
+int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, float* dbias, int M, int N, float p, unsigned long long seed,
+                     float* ws, hipStream_t st) {
+  if (M <= 0 || N <= 0) return VQA_EARG;
+  const BiasBwdGeom g = bias_bwd_geom(dtype, M, N);
+  if (g.vec) {
+    DT(hipLaunchKernelGGL(bias_act_bwd_vec_kernel<float>, g.grid, dim3(256), 0, st, (const float*)dout, (const float*)outact, (float*)dz, dbias, M, N, p, seed, g.rows_per, ws),
+       hipLaunchKernelGGL(bias_act_bwd_vec_kernel<bf16_t>, g.grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (bf16_t*)dz, dbias, M, N, p, seed, g.rows_per, ws));
+  } else {
+    DT(hipLaunchKernelGGL(bias_act_bwd_kernel<float>, g.grid, dim3(256), 0, st, (const float*)dout, (const float*)outact, (float*)dz, dbias, M, N, 0, p, seed, ws),
+       hipLaunchKernelGGL(bias_act_bwd_kernel<bf16_t>, g.grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (bf16_t*)dz, dbias, M, N, 0, p, seed, ws));
+  }
+  if (ws && dbias) launch_fold(ws, (int)g.grid.y, (size_t)N, N, dbias, N, nullptr, st);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
+// ws (B floats or nullptr): the per-row loss terms are summed in row order by a second launch (bit-reproducible); nullptr -> one
+// float atomic per row.  *loss is accumulated into (+=): zero it first.
 int vqa_cross_entropy(int dtype, const void* logits, const long long* targets, float* loss, void* dlogits, float* logits_f32, int B, int N,
-                      float gscale, int* err, hipStream_t st) {
+                      float gscale, int* err, float* ws, hipStream_t st) {
   if (!logits || !targets || B <= 0 || N <= 0) return VQA_EARG;
   dim3 grid((B + 3) / 4);
-  DT(hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, targets, loss, (float*)dlogits, logits_f32, B, N, gscale, err),
-     hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)logits, targets, loss, (bf16_t*)dlogits, logits_f32, B, N, gscale, err));
+  DT(hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, targets, loss, (float*)dlogits, logits_f32, B, N, gscale, err, ws),
+     hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)logits, targets, loss, (bf16_t*)dlogits, logits_f32, B, N, gscale, err, ws));
+  if (ws && loss) launch_fold(ws, B, 1, 1, loss, 1, nullptr, st);        // B "rows" of one column
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // dtype_in / dtype_out: 0 = f32, 1 = bf16

@@ -285,7 +285,10 @@ class HipEngine:
             e = self.E[bname]
             dbias = G[e.offset: e.offset + e.numel]
         if need_dz or dbias is not None:
-            call("vqa_bias_act_bwd", dt(dout), ptr(dout), ptr(outact), ptr(dz), ptr(dbias), M, N, float(p), int(seed))
+            ws = None
+            if dbias is not None:          # fixed-order column sums (bit-reproducible): per-workgroup rows + index-order fold
+                ws = torch.empty((K.reduce_ws("vqa_bias_act_bwd_ws", dt(dout), M, N),), device=dout.device, dtype=torch.float32)
+            call("vqa_bias_act_bwd", dt(dout), ptr(dout), ptr(outact), ptr(dz), ptr(dbias), M, N, float(p), int(seed), ptr(ws))
         return dz if need_dz else dout
 
     def _ln(self, x, prefix, p=0.0, seed=0, addrow=None, period=1):
@@ -698,7 +701,7 @@ class HipEngine:
             if "spatial" in srec:
                 r = srec["spatial"]
                 npix = B * r["H"] * r["W"]
-                scratch = torch.empty((npix * 3,), device=dxc.device, dtype=torch.float32)
+                scratch = torch.empty((K.L.count("vqa_spatial_bwd_scratch", B, r["H"], r["W"]),), device=dxc.device, dtype=torch.float32)
                 dxn = torch.empty_like(r["x"])
                 call("vqa_spatial_bwd", dt(T), ptr(dxc), ptr(r["x"]), ptr(self.P(ap + ".spatial.conv.weight")), ptr(r["pooled2"]),
                      ptr(r["amax"]), ptr(r["amap"]), ptr(scratch), ptr(dxn), ptr(self._gslice(G, ap + ".spatial.conv.weight")),

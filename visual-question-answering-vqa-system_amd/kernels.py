@@ -309,9 +309,27 @@ def layernorm_fwd(x, gamma, beta, *, eps=1e-5, drop_p=0.0, seed=0, addrow=None, 
     return out, stats
 
 
-def layernorm_bwd(dout, x, gamma, stats, dgamma, dbeta, *, addend=None, drop_p=0.0, seed=0, dadd=None, period=1):
+_WS_CACHE = {}
+
+
+def reduce_ws(name, *args):
+    """Scratch floats of a fixed-order reduction entry (vqa_layernorm_bwd_ws / vqa_bias_act_bwd_ws), cached by shape."""
+    key = (name,) + args
+    v = _WS_CACHE.get(key)
+    if v is None:
+        v = _WS_CACHE[key] = int(L.count(name, *args))
+    return v
+
+
+def layernorm_bwd(dout, x, gamma, stats, dgamma, dbeta, *, addend=None, drop_p=0.0, seed=0, dadd=None, period=1, fixed_order=True):
+    """fixed_order: dgamma / dbeta / dadd are summed through per-workgroup partial rows + an index-order fold (bit-reproducible);
+    False -> float atomics."""
     rows, D = x.shape
     dx = torch.empty_like(x)
+    ws = None
+    if fixed_order:
+        ws = torch.empty((reduce_ws("vqa_layernorm_bwd_ws", dt(x), rows, D, period if dadd is not None else 0),),
+                         device=x.device, dtype=torch.float32)
     call("vqa_layernorm_bwd", dt(x), ptr(dout), ptr(x), ptr(gamma), ptr(stats), ptr(addend), ptr(dx), ptr(dgamma), ptr(dbeta),
-         rows, D, float(drop_p), int(seed), ptr(dadd), period)
+         rows, D, float(drop_p), int(seed), ptr(dadd), period, ptr(ws))
     return dx

@@ -106,7 +106,9 @@ class HipTrainer:
         logits_f, _, tape = eng.forward(images, token_ids, maskf, True, False, need_tape=True)
         B, N = logits_f.shape
         dlogits = torch.empty((B, N), device=images.device, dtype=torch.float32)
-        call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0, ptr(self.bad_targets))
+        ce_ws = torch.empty((B,), device=images.device, dtype=torch.float32)
+        call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0, ptr(self.bad_targets),
+             ptr(ce_ws))                                   # per-row loss terms, folded in row order (bit-reproducible)
         if metrics is not None:
             metrics.update(logits_f, targets)
         eng.backward(tape, dlogits, self.G, on_segment=self.reducer.on_segment if self.world > 1 else None)
