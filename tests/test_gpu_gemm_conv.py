@@ -205,7 +205,7 @@ def test_stem_wgrad_bf16_dedicated_kernel(hw):
     assert _relerr(dw.cpu(), w.grad.permute(0, 2, 3, 1).reshape(64, 147)) < 3e-3
 
 
-@pytest.mark.parametrize("case", [(2, 56, 56), (3, 16, 24), (1, 8, 8)])
+@pytest.mark.parametrize("case", [(2, 56, 56), (3, 16, 24), (1, 8, 8), (20, 56, 56)])     # (20,56,56): 280 row blocks > 256 persistent workgroups
 def test_conv3x3_c64_patch_kernels(case):
     """stage-1 LDS-patch kernels (bf16): forward + stats, data gradient with the masked identity addend, weight gradient."""
     K = sub("kernels")

@@ -9,6 +9,7 @@
 //     whole walk, one atomic flush per workgroup.
 // These layers are HBM-bound in bf16 (288 flop/byte); the patch cuts L2/HBM reads ~9x versus a per-tap gather.
 #include <cstdlib>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
 // ------------------------------------------------------------------------------------------------
 // weight gradient: dw[n][(r,s,c)] += sum_px dy[px][n] * x[px + (r-1, s-1)][c]
 // ------------------------------------------------------------------------------------------------
-struct C64WgradParams { const bf16_t* x; const bf16_t* dy; float* dw; float* ws; int B, H, W; unsigned x_bytes, dy_bytes; };
+struct C64WgradParams { const bf16_t* x; const bf16_t* dy; float* dw; float* ws; int B, H, W; unsigned x_bytes, dy_bytes; int dbg; /* VQA_C64WP_DBG, measurement only: bit 1 no MFMA loop, bit 2 no in-loop DMA */ };
 
 __global__ __launch_bounds__(256) void wgrad3x3_c64_kernel(C64WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -460,6 +461,233 @@ __global__ __launch_bounds__(256) void wgrad3x3_c64_kernel(C64WgradParams p) {
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient, 8-wave LDS-DMA form.  Same contraction as wgrad3x3_c64_kernel; what differs:
+//   * both operands of a block (4 output rows: the 6 x (W+2) input patch and the 4 x W tile of dY) arrive by LDS-DMA into a
+//     double buffer, issued one block ahead -- no register staging (the 4-wave kernel spends 80 VGPRs and two barriers per block
+//     on it, and its LDS stores are not overlapped with the MFMAs);
+//   * 8 waves: wave = (c tile of 16 input channels) x (half of the 36 (tap, n tile) accumulators): taps 0-3 + half of tap 4,
+//     or the other half of tap 4 + taps 5-8.  18 accumulators (72 VGPRs) per wave, no cross-wave reduction, equal work;
+//   * both LDS images are XOR-swizzled on the DMA SOURCE side with f(i) = (i & 7) ^ ((i >> 3 & 1) << 2), i = pixel index (dY) or
+//     patch column (x): the transposed reads of a half-wave touch pixels {p..p+3, p+8..p+11}, which the 4-wave kernel's
+//     (col & 7) swizzle maps onto the same banks twice.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int RBW = 4;            // output rows per block
+__device__ __forceinline__ int swz16(int i) { return (i & 7) ^ (((i >> 3) & 1) << 2); }
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+typedef __attribute__((ext_vector_type(2))) int i32x2_c64;
+typedef __attribute__((ext_vector_type(4))) int i32x4v_c64;
+
+template <int KH, int WC>                                      // WC: compile-time image width (address math folds), 0 = runtime
+__device__ __forceinline__ void wgrad_c64p_body(const C64WgradParams& p, char* smem, unsigned lds0) {
+  typedef __attribute__((ext_vector_type(8))) short i16x8;
+  const int Wd = WC ? WC : p.W;
+  const int PWc = Wd + 2;
+  const int patch_bytes = (RBW + 2) * PWc * 128, npx = RBW * Wd, dy_bytes = ((npx + 31) / 32 * 32) * 128;
+  const int buf_bytes = patch_bytes + dy_bytes;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cw = wave & 3;
+  const int rblocks = p.H / RBW, nblocks = p.B * rblocks, nks = (npx + 31) / 32;
+  const unsigned long long xa = (unsigned long long)p.x, ya = (unsigned long long)p.dy;
+  const i32x4_c64 rsX = {(int)(unsigned)xa, (int)((unsigned)(xa >> 32) & 0xffffu), (int)p.x_bytes, 0x00020000};
+  const i32x4_c64 rsY = {(int)(unsigned)ya, (int)((unsigned)(ya >> 32) & 0xffffu), (int)p.dy_bytes, 0x00020000};
+
+  // ---- halo columns of both patch buffers: zero, once (the DMA pieces only ever write columns 1 .. W)
+  for (int i = tid; i < 2 * (RBW + 2) * 2 * 8; i += 512) {
+    const int chunk = i & 7, side = (i >> 3) & 1, prow = (i >> 4) % (RBW + 2), buf = (i >> 4) / (RBW + 2);
+    *reinterpret_cast<u32x4*>(smem + buf * buf_bytes + ((prow * PWc + (side ? PWc - 1 : 0)) * 8 + chunk) * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  // ---- DMA plan.  x: piece (prow, j) = pixels 8j .. 8j+7 of image row oh0 - 1 + prow -> patch columns 1 + 8j ..;
+  //      dY: piece j = pixels 8j .. 8j+7 of the block (rows beyond the block's pixels: out of range -> zeros).
+  const int ppr = Wd >> 3, nxp = (RBW + 2) * ppr, nyp = nks * 4, npieces = nxp + nyp;
+  const int dpx = lane >> 3, dpos = lane & 7;
+  auto issue = [&](int blk, int buf) {
+    const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBW;
+    const unsigned base = lds0 + (unsigned)(buf * buf_bytes);
+    for (int id = wave; id < npieces; id += 8) {
+      if (id < nxp) {
+        const int prow = id / ppr, j = id - prow * ppr, ih = oh0 - 1 + prow;
+        const bool ok = (unsigned)ih < (unsigned)p.H;
+        const int pc = 1 + 8 * j + dpx;
+        dma16_c64(rsX, base + (unsigned)((prow * PWc + 1 + 8 * j) * 128), ok ? dpx * 128 + ((dpos ^ swz16(pc)) << 4) : OOBV,
+                  ok ? ((b * p.H + ih) * Wd + 8 * j) * 128 : 0);
+      } else {
+        const int j = id - nxp, px = 8 * j + dpx;
+        dma16_c64(rsY, base + (unsigned)(patch_bytes + j * 1024), px < npx ? dpx * 128 + ((dpos ^ swz16(px)) << 4) : OOBV,
+                  ((b * p.H + oh0) * Wd + 8 * j) * 128);
+      }
+    }
+  };
+
+  f32x4 acc[18];
+#pragma unroll
+  for (int a = 0; a < 18; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float inv_w = 1.0f / (float)Wd;
+  const int xchunk = cw * 2 + (pp >> 1), sub = (pp & 1) * 4;           // this lane's 4 channels of the wave's c tile
+
+  // ---- WC == 56: absolute LDS byte addresses of every transposed read, held in registers (they follow the buffer toggle).
+  //      x: [ks][pixel row a / b][tap column s], tap row r is the instruction's immediate offset (r * 58 * 128);
+  //      dY: [a / b][n tile i] -- f(pixel) does not depend on ks here (32 pixels per step), ks is the immediate (ks * 4096).
+  constexpr int NKS = WC ? RBW * WC / 32 : 1;
+  unsigned xo[NKS][2][3], yo[2][4];
+  if constexpr (WC != 0) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab) {
+        const int px = ks * 32 + 8 * g + q + 4 * ab, rr = px / WC, cc = px - rr * WC;
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+          xo[ks][ab][s_] = lds0 + (unsigned)(((rr * (WC + 2) + cc + s_) * 128) + ((xchunk ^ swz16(cc + s_)) << 4) + sub * 2);
+      }
+#pragma unroll
+    for (int ab = 0; ab < 2; ++ab) {
+      const int px = 8 * g + q + 4 * ab;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        yo[ab][i] = lds0 + (unsigned)(patch_bytes + px * 128 + (((2 * i + (pp >> 1)) ^ swz16(px)) << 4) + sub * 2);
+    }
+  }
+
+  int blk = blockIdx.x, buf = 0;
+  if (blk < nblocks) issue(blk, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; blk < nblocks; blk += gridDim.x, buf ^= 1) {
+    const int nxt = blk + gridDim.x;
+    if (nxt < nblocks && !(p.dbg & 4)) issue(nxt, buf ^ 1);     // the other buffer: every wave finished reading it at the last barrier
+    if constexpr (WC != 0) {
+      if (p.dbg & 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); continue; }
+      // Hand-issued transposed reads, counted lgkmcnt waits (LDS returns in order).  35 steps = 7 k-steps x 5 taps; at the top of
+      // step n the wave issues group G_n = the x fragment of step n+2 (2 reads) + (taps 0-3) two of the eight dY reads of the
+      // NEXT k-step; step n then needs G_(n-2) complete, i.e. at most |G_(n-1)| + |G_n| reads outstanding.  Left to the compiler
+      // the reads sit one tap ahead with lgkmcnt(0) every other tap: the LDS latency is exposed ~5x per k-step.
+      constexpr int NST = NKS * 5, ROWB = (WC + 2) * 128;
+      i32x2_c64 xl[3], xh[3], al[2][4], ah[2][4];
+#define TRRD(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+      // prologue: dY fragments of k-step 0, x fragments of steps 0 and 1
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { TRRD(al[0][i], yo[0][i], 0); TRRD(ah[0][i], yo[1][i], 0); }
+      static_for([&xl, &xh, &xo](auto N_) {
+        constexpr int n = decltype(N_)::value, t = KH ? 4 + n : n, r = t / 3, s_ = t - r * 3;
+        TRRD(xl[n], xo[0][0][s_], r * ROWB); TRRD(xh[n], xo[0][1][s_], r * ROWB);
+      }, std::make_integer_sequence<int, 2>{});
+      static_for([&xl, &xh, &al, &ah, &xo, &yo, &acc](auto N_) {
+        constexpr int n = decltype(N_)::value, ks = n / 5, tt = n - ks * 5;
+        // ---- G_n
+        {
+          constexpr int m = n + 2 < NST ? n + 2 : n, mk = m / 5, mt = m - mk * 5, t = KH ? 4 + mt : mt, r = t / 3, s_ = t - r * 3;
+          TRRD(xl[(n + 2) % 3], xo[mk][0][s_], r * ROWB); TRRD(xh[(n + 2) % 3], xo[mk][1][s_], r * ROWB);      // (last two steps: dummy re-read)
+        }
+        if constexpr (tt < 4) {
+          constexpr int nk = ks + 1 < NKS ? ks + 1 : ks, nb = (ks + 1) & 1;                                      // (last k-step: dummy)
+          TRRD(al[nb][tt], yo[0][tt], nk * 4096); TRRD(ah[nb][tt], yo[1][tt], nk * 4096);
+        }
+        // ---- wait for G_(n-2) (and, at tt == 0, for this k-step's dY fragments, issued before it)
+        constexpr int size_n = tt < 4 ? 4 : 2, size_p = n == 0 ? 2 : ((tt + 4) % 5 < 4 ? 4 : 2);
+        if constexpr (tt == 0)
+          asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(xl[n % 3]), "+v"(xh[n % 3]), "+v"(al[ks & 1][0]), "+v"(al[ks & 1][1]), "+v"(al[ks & 1][2]),
+                       "+v"(al[ks & 1][3]), "+v"(ah[ks & 1][0]), "+v"(ah[ks & 1][1]), "+v"(ah[ks & 1][2]), "+v"(ah[ks & 1][3]) : "n"(size_n + size_p));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xl[n % 3]), "+v"(xh[n % 3]) : "n"(size_n + size_p));
+        const i32x4v_c64 xv = {xl[n % 3][0], xl[n % 3][1], xh[n % 3][0], xh[n % 3][1]};
+        const bf16x8 bfv = __builtin_bit_cast(bf16x8, xv);
+        constexpr int t = KH ? 4 + tt : tt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (t == 4 && (KH ? i < 2 : i >= 2)) continue;
+          const int a = KH ? (t == 4 ? i - 2 : 2 + 4 * (t - 5) + i) : (t == 4 ? 16 + i : 4 * t + i);
+          const i32x4v_c64 av = {al[ks & 1][i][0], al[ks & 1][i][1], ah[ks & 1][i][0], ah[ks & 1][i][1]};
+          acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), bfv, acc[a], 0, 0, 0);
+        }
+      }, std::make_integer_sequence<int, NST>{});
+#undef TRRD
+      // the addresses follow the buffer toggle
+      const unsigned d = buf ? (unsigned)(-buf_bytes) : (unsigned)buf_bytes;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+          for (int s_ = 0; s_ < 3; ++s_) xo[ks][ab][s_] += d;
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yo[ab][i] += d;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next block's pieces landed (and the dummy reads retired)
+      __builtin_amdgcn_s_barrier();
+      continue;
+    }
+    const bf16_t* patch = reinterpret_cast<const bf16_t*>(smem + buf * buf_bytes);
+    const bf16_t* Dy = reinterpret_cast<const bf16_t*>(smem + buf * buf_bytes + patch_bytes);
+    constexpr int KS_UNROLL = WC ? RBW * WC / 32 : 1;
+#pragma unroll KS_UNROLL
+    for (int ks = 0; ks < (WC ? RBW * WC / 32 : nks); ++ks) {
+      // dY fragments (A operand: 16 output channels x 32 pixels), all four n tiles
+      const int pa = ks * 32 + 8 * g + q, pb = pa + 4;
+      bf16x8 af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = 2 * i + (pp >> 1);
+        i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(Dy + pa * 64 + ((ch ^ swz16(pa)) << 3) + sub));
+        i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(Dy + pb * 64 + ((ch ^ swz16(pb)) << 3) + sub));
+        i16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[i] = __builtin_bit_cast(bf16x8, t);
+      }
+      // patch coordinates of the two pixel rows this lane addresses (clamped inside the block for the zero-padded tail)
+      const int pxa = pa < npx ? pa : npx - 1, pxb = pb < npx ? pb : npx - 1;
+      const int ra = (int)(((float)pxa + 0.5f) * inv_w), ca = pxa - ra * Wd, rb = (int)(((float)pxb + 0.5f) * inv_w), cb = pxb - rb * Wd;
+#pragma unroll
+      for (int tt = 0; tt < 5; ++tt) {
+        const int t = KH ? 4 + tt : tt, r = t / 3, s = t - r * 3;
+        const int cola = ca + s, colb = cb + s;
+        i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(patch + ((ra + r) * PWc + cola) * 64 + ((xchunk ^ swz16(cola)) << 3) + sub));
+        i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(patch + ((rb + r) * PWc + colb) * 64 + ((xchunk ^ swz16(colb)) << 3) + sub));
+        i16x8 t8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8 bfv = __builtin_bit_cast(bf16x8, t8);
+        // accumulator index of (tap t, n tile i): KH 0: taps 0-3 -> 4t+i, tap 4 (i < 2) -> 16+i; KH 1: tap 4 (i >= 2) -> i-2, taps 5-8 -> 2+4(t-5)+i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (t == 4 && (KH ? i < 2 : i >= 2)) continue;
+          const int a = KH ? (t == 4 ? i - 2 : 2 + 4 * (t - 5) + i) : (t == 4 ? 16 + i : 4 * t + i);
+          acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfv, acc[a], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next block's pieces landed
+    __builtin_amdgcn_s_barrier();
+  }
+  // flush: D[i = n][j = c] per tap -> slab[n][(tap*64 + c)] (one slab per workgroup, reduced in slab order by vqa_slab_reduce)
+  float* slab = p.ws + (size_t)blockIdx.x * 64 * 576;
+#pragma unroll
+  for (int tt = 0; tt < 5; ++tt) {
+    const int t = KH ? 4 + tt : tt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (t == 4 && (KH ? i < 2 : i >= 2)) continue;
+      const int a = KH ? (t == 4 ? i - 2 : 2 + 4 * (t - 5) + i) : (t == 4 ? 16 + i : 4 * t + i);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) slab[(size_t)(i * 16 + g * 4 + rr) * 576 + t * 64 + cw * 16 + li] = acc[a][rr];
+    }
+  }
+}
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad3x3_c64p_kernel(C64WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  if (p.W == 56) {                                            // the model's stage-1 width: fully unrolled, constant addressing
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) wgrad_c64p_body<1, 56>(p, smem, lds0);  // waves 4-7
+    else wgrad_c64p_body<0, 56>(p, smem, lds0);                                                    // waves 0-3
+  } else {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) wgrad_c64p_body<1, 0>(p, smem, lds0);
+    else wgrad_c64p_body<0, 0>(p, smem, lds0);
+  }
+}
+
 extern "C" int vqa_slab_reduce(const float* ws, float* dw, int nslabs, long long n, hipStream_t st);
 
 extern "C" {
@@ -522,10 +750,23 @@ int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int
   if (!x || !dy || !dw || grid <= 0) return VQA_EARG;
   C64WgradParams p;
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.B = B; p.H = H; p.W = W;
+  static const int dbg_env = getenv("VQA_C64WP_DBG") ? atoi(getenv("VQA_C64WP_DBG")) : 0;
+  p.dbg = dbg_env;
   p.ws = (ws && ws_floats >= (long long)grid * 64 * 576) ? ws : nullptr;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)xb;
+  // 8-wave LDS-DMA form (needs the slab workspace: it has no atomic flush); VQA_C64WP=0 keeps the 4-wave kernel (measurement)
+  static const int wp_env = getenv("VQA_C64WP") ? atoi(getenv("VQA_C64WP")) : 1;
+  const size_t shm_p = (size_t)2 * ((size_t)(RBW + 2) * (W + 2) * 128 + (size_t)((RBW * W + 31) / 32 * 32) * 128);
+  const int nblk_p = B * (H / RBW), grid_p = nblk_p < 256 ? nblk_p : 256;
+  if (wp_env && p.ws && H % RBW == 0 && W % 8 == 0 && shm_p <= 160 * 1024 && grid_p <= grid) {
+    static size_t attr_p = 0;
+    if (shm_p > attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_c64p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_p); attr_p = shm_p; }
+    hipLaunchKernelGGL(wgrad3x3_c64p_kernel, dim3(grid_p), dim3(512), shm_p, st, p);
+    VQA_LAUNCH_CHECK();
+    return vqa_slab_reduce(p.ws, dw, grid_p, 64 * 576, st);
+  }
   const int MP = (RBG * W + 31) / 32 * 32;
   const size_t shm = (size_t)(RBG + 2) * (W + 2) * CH * 2 + (size_t)MP * (CH + 4) * 2;
   static size_t attr = 0;

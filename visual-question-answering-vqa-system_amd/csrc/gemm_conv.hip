@@ -1232,6 +1232,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   reinterpret_cast<f32x4*>(dw)[i] = a;
 }
 
+// Same sum for many slabs of a SMALL gradient (64x576 from 256 workgroups, 128x1152 from 112 splits): one thread per float4 walks
+// every slab in a dependent-latency loop there (64 rounds of 4 loads) while most CUs idle.  Here a block is 64 float4 columns x 16
+// slab groups; group g sums its contiguous run of slabs in slab order, the 16 group sums are folded in group order through LDS:
+// still one fixed summation order (bit-reproducible), 16x shorter chains, 16x more workgroups.
+__global__ __launch_bounds__(1024) void wgrad_reduce2_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const int gq = threadIdx.y, per = (nsplit + 15) / 16, s0 = gq * per, s1 = min(nsplit, s0 + per);
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(ws);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (i < total4) {
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      const f32x4 v0 = w4[(size_t)s * total4 + i], v1 = w4[(size_t)(s + 1) * total4 + i];
+      const f32x4 v2 = w4[(size_t)(s + 2) * total4 + i], v3 = w4[(size_t)(s + 3) * total4 + i];
+      a += v0; a += v1; a += v2; a += v3;
+    }
+    for (; s < s1; ++s) a += w4[(size_t)s * total4 + i];
+  }
+  __shared__ f32x4 sh[16][64];
+  sh[gq][threadIdx.x] = a;
+  __syncthreads();
+  if (gq == 0 && i < total4) {
+    f32x4 t = reinterpret_cast<const f32x4*>(dw)[i];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q][threadIdx.x];
+    reinterpret_cast<f32x4*>(dw)[i] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight packing: cast (+row pad) and [N][T][C] -> [C][T][N] transpose for the data-gradient GEMM
 // ------------------------------------------------------------------------------------------------
@@ -1428,7 +1457,10 @@ static int launch_wgrad(const WgradParams& p, int nsplit, hipStream_t st) {
 
 static int launch_reduce(const WgradParams& p, int nsplit, hipStream_t st) {
   const size_t total4 = (size_t)p.N * p.Kw / 4;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, p.ws, p.dw, nsplit, total4);
+  if (nsplit >= 32 && total4 <= 256 * 1024)        // few columns, many slabs: see wgrad_reduce2_kernel (choice depends on the shape only)
+    hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(64, 16), 0, st, p.ws, p.dw, nsplit, total4);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, p.ws, p.dw, nsplit, total4);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }
@@ -1701,7 +1733,11 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
 int vqa_slab_reduce(const float* ws, float* dw, int nslabs, long long n, hipStream_t st) {
   if (!ws || !dw || nslabs <= 0 || n <= 0 || (n % 4)) return VQA_EARG;
   const size_t total4 = (size_t)n / 4;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, ws, dw, nslabs, total4);
+  // few columns, many slabs: split the slab walk over 16 thread groups (fixed fold order); the choice depends on the shape only
+  if (nslabs >= 32 && total4 <= 256 * 1024)
+    hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(64, 16), 0, st, ws, dw, nslabs, total4);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, ws, dw, nslabs, total4);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }
