@@ -235,40 +235,66 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // Stem tail: BN + ReLU + MaxPool3x3/2 p1 fused (the 112x112 activation is never written)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void stem_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef, T* __restrict__ out,
-                                     uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef, T* __restrict__ out,
+                                                            uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo) {
+  // A thread owns one channel vector of TWO horizontally adjacent outputs: their 3x3/2 windows share a column, so 15 loads
+  // (BN + ReLU applied once each) serve 2 outputs instead of 18; the argmax bytes of an output leave as one packed store.
   constexpr int VEC = Vec16<T>::N;
-  const int cv = C / VEC;
-  const size_t total = (size_t)B * Ho * Wo * cv;
+  const int cv = C / VEC, Wp = (Wo + 1) >> 1;
+  const size_t total = (size_t)B * Ho * Wp * cv;
   const int c0 = (int)(threadIdx.x % cv) * VEC;          // fixed per thread: 256 and the grid stride are multiples of cv
   float sc[VEC], sh[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { sc[j] = coef[c0 + j]; sh[j] = coef[C + c0 + j]; }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t p = i / cv;
-    const int ow = (int)(p % Wo); p /= Wo; const int oh = (int)(p % Ho); const int b = (int)(p / Ho);
-    float best[VEC]; int bi[VEC];
+    const int owp = (int)(p % Wp); p /= Wp; const int oh = (int)(p % Ho); const int b = (int)(p / Ho);
+    const int ow0 = owp * 2;
+    const bool two = ow0 + 1 < Wo;
+    float best[2][VEC]; int bi[2][VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { best[o][j] = -INFINITY; bi[o][j] = 0; }
+#pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int ih = oh * 2 - 1 + r;
       if (ih < 0 || ih >= H) continue;
-      for (int s = 0; s < 3; ++s) {
-        const int iw = ow * 2 - 1 + s;
-        if (iw < 0 || iw >= W) continue;
-        Vec16<T> yy = ldg16(y + (((size_t)b * H + ih) * W + iw) * C + c0);
+      const T* yr = y + (((size_t)b * H + ih) * W) * C + c0;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          float a = yy.get(j) * sc[j] + sh[j];
-          a = a < 0.f ? 0.f : a;
-          if (a > best[j] || a != a) { best[j] = a; bi[j] = r * 3 + s; }     // first max wins, NaN propagates (ATen max_pool2d)
+      for (int s5 = 0; s5 < 5; ++s5) {                       // input columns 2*ow0 - 1 .. 2*ow0 + 3
+        const int iw = ow0 * 2 - 1 + s5;
+        if (iw < 0 || iw >= W) continue;
+        const Vec16<T> yy = ldg16(yr + (size_t)iw * C);
+        float a[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { const float t = yy.get(j) * sc[j] + sh[j]; a[j] = t < 0.f ? 0.f : t; }
+        if (s5 < 3) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            if (a[j] > best[0][j] || a[j] != a[j]) { best[0][j] = a[j]; bi[0][j] = r * 3 + s5; }     // first max wins, NaN propagates (ATen max_pool2d)
+        }
+        if (s5 >= 2) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            if (a[j] > best[1][j] || a[j] != a[j]) { best[1][j] = a[j]; bi[1][j] = r * 3 + s5 - 2; }
         }
       }
     }
-    Vec16<T> o;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { o.set(j, best[j]); idx[i * VEC + j] = (uint8_t)bi[j]; }
-    stg16(out + i * VEC, o);
+    for (int o = 0; o < 2; ++o) {
+      if (o == 1 && !two) break;
+      const size_t e = ((((size_t)b * Ho + oh) * Wo + ow0 + o) * C + c0);
+      Vec16<T> ov;
+      uint32_t pk[VEC / 4];
+#pragma unroll
+      for (int q4 = 0; q4 < VEC / 4; ++q4) pk[q4] = 0u;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { ov.set(j, best[o][j]); pk[j >> 2] |= (uint32_t)bi[o][j] << (8 * (j & 3)); }
+      stg16(out + e, ov);
+#pragma unroll
+      for (int q4 = 0; q4 < VEC / 4; ++q4) reinterpret_cast<uint32_t*>(idx + e)[q4] = pk[q4];
+    }
   }
 }
 
@@ -749,7 +775,7 @@ int vqa_bn_bwd_apply(int dtype, const void* dout, const void* outact, const void
 int vqa_stem_pool_fwd(int dtype, const void* y, const float* coef, void* out, uint8_t* idx, int B, int H, int W, int C, hipStream_t st) {
   const int VEC = dtype ? 8 : 4, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   if (C % 8) return VQA_EARG;
-  const size_t total = (size_t)B * Ho * Wo * (C / VEC);
+  const size_t total = (size_t)B * Ho * ((Wo + 1) / 2) * (C / VEC);
   DT(hipLaunchKernelGGL(stem_pool_fwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, st, (const float*)y, coef, (float*)out, idx, B, H, W, C, Ho, Wo),
      hipLaunchKernelGGL(stem_pool_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, st, (const bf16_t*)y, coef, (bf16_t*)out, idx, B, H, W, C, Ho, Wo));
   VQA_LAUNCH_CHECK(); return VQA_OK;

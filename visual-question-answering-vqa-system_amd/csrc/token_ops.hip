@@ -84,10 +84,19 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
     // thread t owns rows base + 4t .. base + 4t + 3 (row order == thread order, then k)
     int hit[4];
     int nh = 0;
+    long long idv[4];
+    const int rb = base + threadIdx.x * 4;
+    if (rb + 3 < rows) {                                      // two 16-byte loads (ids is 8-byte aligned, rb is a multiple of 4)
+      const u32x4 lo = *reinterpret_cast<const u32x4*>(ids + rb), hi = *reinterpret_cast<const u32x4*>(ids + rb + 2);
+      idv[0] = (long long)(((unsigned long long)lo[1] << 32) | lo[0]); idv[1] = (long long)(((unsigned long long)lo[3] << 32) | lo[2]);
+      idv[2] = (long long)(((unsigned long long)hi[1] << 32) | hi[0]); idv[3] = (long long)(((unsigned long long)hi[3] << 32) | hi[2]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) idv[k] = rb + k < rows ? ids[rb + k] : -1;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int r = base + threadIdx.x * 4 + k;
-      const long long id = r < rows ? ids[r] : -1;
+      const long long id = idv[k];
       const bool h = id >= v0 && id < v0 + EMB_VB && id > 0 && id < V;       // padding_idx = 0 receives no gradient
       hit[k] = h ? (int)(id - v0) : -1;
       nh += h;
@@ -105,13 +114,21 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
     for (int k = 0; k < 4; ++k)
       if (hit[k] >= 0) list[off++] = ((base + threadIdx.x * 4 + k) << 4) | hit[k];
     __syncthreads();
-    for (int i = 0; i < total; ++i) {
-      const int e = list[i], row = e >> 4, slot = e & 15;
+    for (int i0 = 0; i0 < total; i0 += 8) {                   // 8 matching rows in flight, added in list order
       for (int d = threadIdx.x; d < D; d += 256) {
-        const size_t o = (size_t)row * D + d;
-        float g = to_f<T>(dout[o]) * scale;
-        if (p > 0.f) g = drop_keep32(dkey, (uint32_t)o, p) ? g * ks : 0.f;
-        eacc[slot * D + d] += g;                             // column d is only ever touched by this thread
+        float gq[8]; int sl[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = list[i0 + u < total ? i0 + u : total - 1], row = e >> 4;
+          sl[u] = i0 + u < total ? (e & 15) : -1;
+          const size_t o = (size_t)row * D + d;
+          float g = to_f<T>(dout[o]) * scale;
+          if (p > 0.f) g = drop_keep32(dkey, (uint32_t)o, p) ? g * ks : 0.f;
+          gq[u] = g;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (sl[u] >= 0) eacc[sl[u] * D + d] += gq[u];      // column d is only ever touched by this thread
       }
     }
     any |= total > 0;
