@@ -4,7 +4,7 @@
 Properties: (a) eval-mode logits of a sample do not depend on the rest of the batch, and the first samples of the big batch
 match the CPU oracle run on just those samples (ties the full-size run to the pinned oracle); (b) the last-layer bias
 gradient sums to zero (softmax - onehot sums to zero per row); (c) everything stays finite, parameters move, BN buffers
-update; (d) two identical steps from identical state give bit-identical parameters (no run-to-run drift in the update)."""
+update; (d) two identical steps from identical state give bit-identical loss, gradients and parameters (fixed-order reductions everywhere)."""
 import numpy as np
 import pytest
 import torch
@@ -85,9 +85,9 @@ def test_full_size_train_step_invariants(dtype, B):
     assert int(st["image_encoder.stage4.blocks.1.bn2.num_batches_tracked"]) == 1
     assert not torch.equal(st["image_encoder.stem.1.running_mean"].cpu(), sd["image_encoder.stem.1.running_mean"])
     assert not torch.equal(st["answer_head.classifier.6.weight"].cpu(), sd["answer_head.classifier.6.weight"])      # parameters moved
-    # same state, same batch, same dropout seed -> same clip factor; weight-gradient atomics may reorder last bits only
+    # same state, same batch, same dropout seed: every gradient is a fixed-order sum (no float atomics on the gradient path), so a second
+    # run from the same state is bit-identical at the full benchmark size too -- loss, gradient buffer and updated parameters
     m2, tr2, loss2, _ = run()
-    assert abs(loss - loss2) < 1e-4
-    # (AdamW's first step moves every weight by ~lr*sign(g): a gradient element at the noise floor may flip sign, so compare in bulk)
-    diff = (m._flat - m2._flat).abs()
-    assert diff.max().item() <= 2.5e-4 and (diff > 1e-6).float().mean().item() < 1e-3
+    assert loss == loss2
+    assert torch.equal(tr.G, tr2.G)
+    assert torch.equal(m._flat, m2._flat)

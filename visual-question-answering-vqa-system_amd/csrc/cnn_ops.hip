@@ -234,67 +234,73 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // ---------------------------------------------------------------------------------------------
 // Stem tail: BN + ReLU + MaxPool3x3/2 p1 fused (the 112x112 activation is never written)
 // ---------------------------------------------------------------------------------------------
+// A workgroup owns a tile of 4 output rows x 7 output pairs (14 columns) x all channel vectors: its 9 x 29 input pixels are
+// fetched once per tile through the CU's caches (1.13x the tensor); a row-major walk over the outputs fetched every input row for
+// two output rows from HBM (PMC: 1.5x).  A thread owns one channel vector of TWO horizontally adjacent outputs: their 3x3/2
+// windows share a column, so 15 loads (BN + ReLU applied once each) serve 2 outputs; the argmax bytes leave as packed stores.
+constexpr int SP_ROWS = 4, SP_PAIRS = 7;
 template <typename T>
 __global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef, T* __restrict__ out,
-                                                            uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo) {
-  // A thread owns one channel vector of TWO horizontally adjacent outputs: their 3x3/2 windows share a column, so 15 loads
-  // (BN + ReLU applied once each) serve 2 outputs instead of 18; the argmax bytes of an output leave as one packed store.
+                                                            uint8_t* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo, int trows) {
   constexpr int VEC = Vec16<T>::N;
   const int cv = C / VEC, Wp = (Wo + 1) >> 1;
-  const size_t total = (size_t)B * Ho * Wp * cv;
-  const int c0 = (int)(threadIdx.x % cv) * VEC;          // fixed per thread: 256 and the grid stride are multiples of cv
+  const int tiles_x = (Wp + SP_PAIRS - 1) / SP_PAIRS, tiles_y = (Ho + trows - 1) / trows;
+  const int per_row = SP_PAIRS * cv;                       // threads per output row of the tile (host: per_row * trows <= 256)
+  const int ry = threadIdx.x / per_row, rem = threadIdx.x - ry * per_row;
+  if (ry >= trows) return;
+  const int pr = rem / cv, c0 = (rem - pr * cv) * VEC;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x; t /= tiles_x; const int ty = t % tiles_y; const int b = t / tiles_y;
+  const int oh = ty * trows + ry, owp = tx * SP_PAIRS + pr;
+  if (oh >= Ho || owp >= Wp) return;
   float sc[VEC], sh[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { sc[j] = coef[c0 + j]; sh[j] = coef[C + c0 + j]; }
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    size_t p = i / cv;
-    const int owp = (int)(p % Wp); p /= Wp; const int oh = (int)(p % Ho); const int b = (int)(p / Ho);
-    const int ow0 = owp * 2;
-    const bool two = ow0 + 1 < Wo;
-    float best[2][VEC]; int bi[2][VEC];
+  const int ow0 = owp * 2;
+  const bool two = ow0 + 1 < Wo;
+  float best[2][VEC]; int bi[2][VEC];
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+  for (int o = 0; o < 2; ++o)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { best[o][j] = -INFINITY; bi[o][j] = 0; }
+    for (int j = 0; j < VEC; ++j) { best[o][j] = -INFINITY; bi[o][j] = 0; }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int ih = oh * 2 - 1 + r;
-      if (ih < 0 || ih >= H) continue;
-      const T* yr = y + (((size_t)b * H + ih) * W) * C + c0;
+  for (int r = 0; r < 3; ++r) {
+    const int ih = oh * 2 - 1 + r;
+    if (ih < 0 || ih >= H) continue;
+    const T* yr = y + (((size_t)b * H + ih) * W) * C + c0;
 #pragma unroll
-      for (int s5 = 0; s5 < 5; ++s5) {                       // input columns 2*ow0 - 1 .. 2*ow0 + 3
-        const int iw = ow0 * 2 - 1 + s5;
-        if (iw < 0 || iw >= W) continue;
-        const Vec16<T> yy = ldg16(yr + (size_t)iw * C);
-        float a[VEC];
+    for (int s5 = 0; s5 < 5; ++s5) {                         // input columns 2*ow0 - 1 .. 2*ow0 + 3
+      const int iw = ow0 * 2 - 1 + s5;
+      if (iw < 0 || iw >= W) continue;
+      const Vec16<T> yy = ldg16(yr + (size_t)iw * C);
+      float a[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { const float t = yy.get(j) * sc[j] + sh[j]; a[j] = t < 0.f ? 0.f : t; }
-        if (s5 < 3) {
+      for (int j = 0; j < VEC; ++j) { const float v = yy.get(j) * sc[j] + sh[j]; a[j] = v < 0.f ? 0.f : v; }
+      if (s5 < 3) {
 #pragma unroll
-          for (int j = 0; j < VEC; ++j)
-            if (a[j] > best[0][j] || a[j] != a[j]) { best[0][j] = a[j]; bi[0][j] = r * 3 + s5; }     // first max wins, NaN propagates (ATen max_pool2d)
-        }
-        if (s5 >= 2) {
+        for (int j = 0; j < VEC; ++j)
+          if (a[j] > best[0][j] || a[j] != a[j]) { best[0][j] = a[j]; bi[0][j] = r * 3 + s5; }     // first max wins, NaN propagates (ATen max_pool2d)
+      }
+      if (s5 >= 2) {
 #pragma unroll
-          for (int j = 0; j < VEC; ++j)
-            if (a[j] > best[1][j] || a[j] != a[j]) { best[1][j] = a[j]; bi[1][j] = r * 3 + s5 - 2; }
-        }
+        for (int j = 0; j < VEC; ++j)
+          if (a[j] > best[1][j] || a[j] != a[j]) { best[1][j] = a[j]; bi[1][j] = r * 3 + s5 - 2; }
       }
     }
+  }
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      if (o == 1 && !two) break;
-      const size_t e = ((((size_t)b * Ho + oh) * Wo + ow0 + o) * C + c0);
-      Vec16<T> ov;
-      uint32_t pk[VEC / 4];
+  for (int o = 0; o < 2; ++o) {
+    if (o == 1 && !two) break;
+    const size_t e = ((((size_t)b * Ho + oh) * Wo + ow0 + o) * C + c0);
+    Vec16<T> ov;
+    uint32_t pk[VEC / 4];
 #pragma unroll
-      for (int q4 = 0; q4 < VEC / 4; ++q4) pk[q4] = 0u;
+    for (int q4 = 0; q4 < VEC / 4; ++q4) pk[q4] = 0u;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { ov.set(j, best[o][j]); pk[j >> 2] |= (uint32_t)bi[o][j] << (8 * (j & 3)); }
-      stg16(out + e, ov);
+    for (int j = 0; j < VEC; ++j) { ov.set(j, best[o][j]); pk[j >> 2] |= (uint32_t)bi[o][j] << (8 * (j & 3)); }
+    stg16(out + e, ov);
 #pragma unroll
-      for (int q4 = 0; q4 < VEC / 4; ++q4) reinterpret_cast<uint32_t*>(idx + e)[q4] = pk[q4];
-    }
+    for (int q4 = 0; q4 < VEC / 4; ++q4) reinterpret_cast<uint32_t*>(idx + e)[q4] = pk[q4];
   }
 }
 
@@ -774,10 +780,15 @@ int vqa_bn_bwd_apply(int dtype, const void* dout, const void* outact, const void
 
 int vqa_stem_pool_fwd(int dtype, const void* y, const float* coef, void* out, uint8_t* idx, int B, int H, int W, int C, hipStream_t st) {
   const int VEC = dtype ? 8 : 4, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  if (C % 8) return VQA_EARG;
-  const size_t total = (size_t)B * Ho * ((Wo + 1) / 2) * (C / VEC);
-  DT(hipLaunchKernelGGL(stem_pool_fwd_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, st, (const float*)y, coef, (float*)out, idx, B, H, W, C, Ho, Wo),
-     hipLaunchKernelGGL(stem_pool_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, st, (const bf16_t*)y, coef, (bf16_t*)out, idx, B, H, W, C, Ho, Wo));
+  const int per_row = SP_PAIRS * (C / VEC);
+  if (C % 8 || per_row > 256) return VQA_EARG;
+  const int trows = 256 / per_row < SP_ROWS ? 256 / per_row : SP_ROWS;      // 4 rows (bf16, C = 64), 2 (fp32)
+  const int Wp = (Wo + 1) / 2;
+  const long long tiles = (long long)B * ((Ho + trows - 1) / trows) * ((Wp + SP_PAIRS - 1) / SP_PAIRS);
+  if (tiles <= 0 || tiles > 0x7fffffffll) return VQA_EARG;
+  const int threads = (per_row * trows + 63) / 64 * 64;
+  DT(hipLaunchKernelGGL(stem_pool_fwd_kernel<float>, dim3((unsigned)tiles), dim3(threads), 0, st, (const float*)y, coef, (float*)out, idx, B, H, W, C, Ho, Wo, trows),
+     hipLaunchKernelGGL(stem_pool_fwd_kernel<bf16_t>, dim3((unsigned)tiles), dim3(threads), 0, st, (const bf16_t*)y, coef, (bf16_t*)out, idx, B, H, W, C, Ho, Wo, trows));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_stem_bwd_reduce(int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* coef, float* slab, int B, int H, int W, int C, hipStream_t st) {
