@@ -68,6 +68,13 @@ int vqa_conv3x3_c64p_blocks(int B, int H, int W);
 int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, hipStream_t stream);
 int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw /* [64][576] += */, int B, int H, int W,
                      float* ws /* >= vqa_conv3x3_c64_blocks * 64*576 floats of scratch, or NULL: atomics */, long long ws_floats, hipStream_t stream);
+/* Up to 8 Linear weight gradients dw_j[N_j][K_j] += dy_j[M_j][N_j]^T x_j[M_j][K_j] in ONE launch + ONE fixed-order reduce launch
+   (training/train.py:196 loss.backward() -> the token-side nn.Linear weights of models/text_encoder.py, cross_attention.py, fusion.py,
+   answer_head.py).  Each dw_j is bit-identical to its own vqa_wgrad call.  vqa_wgrad_group_ws: floats of the shared workspace, or -1
+   when a job is not one the planner gives the 4-wave 128x128 split kernel (the caller then uses vqa_wgrad). */
+long long vqa_wgrad_group_ws(int dtype, int njobs, const int* M, const int* N, const int* Kw);
+int vqa_wgrad_group(int dtype, int njobs, const void* const* dy, const void* const* x, float* const* dw, const int* M, const int* N,
+                    const int* Kw, float* ws, long long ws_floats, hipStream_t stream);
 /* second pass of the deterministic split weight gradients: dw[i] += sum_s ws[s][i] in slab order (n % 4 == 0) */
 int vqa_slab_reduce(const float* ws, float* dw, int nslabs, long long n, hipStream_t stream);
 /* data gradient of a stride-2 conv (+ the block's 1x1/2 shortcut, models/cnn_backbone.py:243-247) in one launch; rows are

@@ -210,3 +210,36 @@ def test_data_gradient_epilogue_reduces_batchnorm_backward_sums(case, dtype):
     if dual:
         ref2 = (gq * (y2.float() - coef2[2]) * coef2[3]).sum(0)
         assert (s[2] - ref2).abs().max().item() < tol(ref2)
+
+
+def test_grouped_linear_weight_gradients_equal_single_launches():
+    """vqa_wgrad_group (up to 8 token-side Linear weight gradients in one launch + one fixed-order reduce) against vqa_wgrad per
+    job: bit-identical (same tiles, splits and slab order), and against torch on the bf16-rounded operands."""
+    K = sub("kernels")
+    T = torch.bfloat16
+    g = torch.Generator().manual_seed(77)
+    shapes = [(10240, 768, 256), (10240, 256, 256), (10240, 1024, 256), (10240, 256, 1024), (25088, 512, 256), (25088, 256, 512),
+              (10240, 256, 256), (512 * 20, 256, 256)]
+    jobs, singles, refs = [], [], []
+    for M, N, Kw in shapes:
+        assert K.wgrad_group_ok(T, M, N, Kw), (M, N, Kw)
+        dy = (torch.randn(M, N, generator=g) * 0.1).to(T)
+        x = torch.randn(M, Kw, generator=g).to(T)
+        dyd, xd = dy.to(DEV), x.to(DEV)
+        dw_g = torch.full((N, Kw), 0.5, device=DEV)                       # += semantics: start from a non-zero buffer
+        dw_s = torch.full((N, Kw), 0.5, device=DEV)
+        jobs.append((dyd, xd, dw_g, M, N, Kw))
+        singles.append((dyd, xd, dw_s, M, N, Kw))
+        refs.append((dy, x))
+    K.wgrad_group(jobs, dtype=T)
+    for dyd, xd, dw_s, M, N, Kw in singles:
+        K.wgrad(dyd, xd, dw_s, M, N, Kw, K.linear_geom(M, Kw), dtype=T)
+    torch.cuda.synchronize()
+    for (dyd, xd, dw_g, M, N, Kw), (_, _, dw_s, *_), (dy, x) in zip(jobs, singles, refs):
+        assert torch.equal(dw_g, dw_s), (M, N, Kw)
+        ref = dy.float().t() @ x.float() + 0.5
+        assert float((dw_g.cpu() - ref).abs().max() / ref.abs().max()) < 2e-3, (M, N, Kw)
+    assert not K.wgrad_group_ok(T, 512, 1000, 256)                         # one split: goes through vqa_wgrad
+    # two jobs, and the engine's fallback for a single job
+    K.wgrad_group(jobs[:2], dtype=T)
+    torch.cuda.synchronize()

@@ -765,7 +765,7 @@ template <typename T, int WIDTH> __device__ __forceinline__ int kmaj_off(int k, 
 }
 
 template <typename T, int BMW, int BNW, int LOADER>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, int bx_in, int by_in, int gx_in, int gy_in) {
   using G = GT<T>;
   constexpr int VEC = G::VEC, BKM = G::BKM;
   constexpr int LDY = (sizeof(T) == 2) ? BMW : BMW + VEC, LDX = (sizeof(T) == 2) ? BNW : BNW + VEC;
@@ -782,9 +782,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int tiles_k = (p.Kw + BNW - 1) / BNW;
   // XCD-aware order (see igemm_kernel): the workgroups of one XCD take a contiguous range of (split, tile) pairs, so the tiles
   // that read the same rows of dY / X (one split-K chunk) share that XCD's L2 instead of filling all eight
-  int bx = blockIdx.x, by = blockIdx.y;
+  int bx = bx_in, by = by_in;
   if (!(p.dbg_noatomic & 2)) {
-    const int gx = gridDim.x, nt = gx * gridDim.y, lin = by * gx + bx;
+    const int gx = gx_in, nt = gx * gy_in, lin = by * gx + bx;
     const int fl = nt >> 3, rem = nt & 7, xcd = lin & 7;
     const int l2 = xcd * fl + (xcd < rem ? xcd : rem) + (lin >> 3);
     by = l2 / gx; bx = l2 - by * gx;
@@ -986,6 +986,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         }
   }
 }
+
+template <typename T, int BMW, int BNW, int LOADER>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  wgrad_body<T, BMW, BNW, LOADER>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+// Several independent weight gradients in ONE launch (the token-side Linears: M ~ 10^4 rows, 40-160 workgroups and ~20 us of
+// dependent latency each -- launched one by one they leave most CUs idle).  Workgroup b belongs to the job whose block range
+// holds b; inside the job it is the (tile, split) workgroup it would have been in its own launch, XCD order included.
+constexpr int WG_MAXJOBS = 8;
+struct WgradGroup { WgradParams p[WG_MAXJOBS]; int blk0[WG_MAXJOBS + 1]; int gx[WG_MAXJOBS]; int gy[WG_MAXJOBS]; int n; };
+template <typename T, int BMW, int BNW, int LOADER>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroup g) {
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < WG_MAXJOBS; ++q) if (q < g.n && (int)blockIdx.x >= g.blk0[q]) j = q;
+  const int local = (int)blockIdx.x - g.blk0[j], gx = g.gx[j];
+  wgrad_body<T, BMW, BNW, LOADER>(g.p[j], local % gx, local / gx, gx, g.gy[j]);
+}
+struct ReduceGroup { const float* ws[WG_MAXJOBS]; float* dw[WG_MAXJOBS]; int nsplit[WG_MAXJOBS]; unsigned total4[WG_MAXJOBS]; int blk0[WG_MAXJOBS + 1]; int n; };
 
 // ------------------------------------------------------------------------------------------------
 // weight gradient, bf16 throughput path: LDS-DMA ring, 8 waves, one workgroup per CU, deterministic two-pass split-K
@@ -1261,6 +1281,26 @@ __global__ __launch_bounds__(1024) void wgrad_reduce2_kernel(const float* __rest
   }
 }
 
+// fixed-order slab sums of a group of weight gradients in one launch (see wgrad_group_kernel)
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(ReduceGroup g) {
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < WG_MAXJOBS; ++q) if (q < g.n && (int)blockIdx.x >= g.blk0[q]) j = q;
+  const size_t total4 = g.total4[j], i = (size_t)((int)blockIdx.x - g.blk0[j]) * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(g.ws[j]);
+  const int nsplit = g.nsplit[j];
+  f32x4 a = reinterpret_cast<const f32x4*>(g.dw[j])[i];
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    const f32x4 v0 = w4[(size_t)s * total4 + i], v1 = w4[(size_t)(s + 1) * total4 + i];
+    const f32x4 v2 = w4[(size_t)(s + 2) * total4 + i], v3 = w4[(size_t)(s + 3) * total4 + i];
+    a += v0; a += v1; a += v2; a += v3;
+  }
+  for (; s < nsplit; ++s) a += w4[(size_t)s * total4 + i];
+  reinterpret_cast<f32x4*>(g.dw[j])[i] = a;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight packing: cast (+row pad) and [N][T][C] -> [C][T][N] transpose for the data-gradient GEMM
 // ------------------------------------------------------------------------------------------------
@@ -1455,6 +1495,20 @@ static int launch_wgrad(const WgradParams& p, int nsplit, hipStream_t st) {
   return VQA_OK;
 }
 
+template <typename T>
+static int launch_wgrad_group(const WgradGroup& g, const ReduceGroup& r, hipStream_t st) {
+  constexpr int VEC = GT<T>::VEC;
+  constexpr int SMEM = 2 * GT<T>::BKM * (128 + 128 + (sizeof(T) == 2 ? 0 : 2 * VEC)) * (int)sizeof(T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<T, 128, 128, LOADER_NHWC>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_group_kernel<T, 128, 128, LOADER_NHWC>), dim3(g.blk0[g.n]), dim3(256), SMEM, st, g);
+  hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(r.blk0[r.n]), dim3(256), 0, st, r);
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
+}
 static int launch_reduce(const WgradParams& p, int nsplit, hipStream_t st) {
   const size_t total4 = (size_t)p.N * p.Kw / 4;
   if (nsplit >= 32 && total4 <= 256 * 1024)        // few columns, many slabs: see wgrad_reduce2_kernel (choice depends on the shape only)
@@ -1726,6 +1780,49 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
   else rc = dtype ? launch_wgrad<bf16_t, 64, 64, LOADER_NHWC>(p, ns, st) : launch_wgrad<float, 64, 64, LOADER_NHWC>(p, ns, st);
   if (rc != VQA_OK) return rc;
   return p.ws ? launch_reduce(p, ns, st) : VQA_OK;
+}
+
+// ---- grouped Linear weight gradients: dw_j[N_j][K_j] += dy_j[M_j][N_j]^T x_j[M_j][K_j], j < njobs <= 8, ONE launch + ONE reduce launch.
+// Every job must be one the planner gives the 4-wave 128x128 kernel with a split workspace (the token-side Linears); the value of
+// each dw_j is bit-identical to its own vqa_wgrad call (same tiles, same splits, same slab order).
+// vqa_wgrad_group_ws: floats of the shared workspace, or -1 when a job does not qualify (the caller then launches one by one).
+static bool wgrad_group_plan(int dtype, int M, int N, int Kw, WgradPlan* pl) {
+  if (M <= 0 || N <= 0 || Kw <= 0 || (N % (dtype ? 8 : 4)) || (Kw % (dtype ? 8 : 4))) return false;
+  *pl = wgrad_plan(dtype, LOADER_NHWC, M, N, Kw, M, 1, 1, Kw, 1, 1, true);
+  return pl->kind == 0 && pl->tn == 128 && pl->tk == 128 && pl->ws_floats > 0 && (pl->ws_floats % 4) == 0 &&
+         (size_t)M * N * (dtype ? 2 : 4) < 0x7fffffffull && (size_t)M * Kw * (dtype ? 2 : 4) < 0x7fffffffull && (long)M < (1l << 23);
+}
+long long vqa_wgrad_group_ws(int dtype, int njobs, const int* M, const int* N, const int* Kw) {
+  if (njobs <= 0 || njobs > WG_MAXJOBS || !M || !N || !Kw) return -1;
+  long long tot = 0;
+  for (int j = 0; j < njobs; ++j) { WgradPlan pl; if (!wgrad_group_plan(dtype, M[j], N[j], Kw[j], &pl)) return -1; tot += pl.ws_floats; }
+  return tot;
+}
+int vqa_wgrad_group(int dtype, int njobs, const void* const* dy, const void* const* x, float* const* dw, const int* M, const int* N,
+                    const int* Kw, float* ws, long long ws_floats, hipStream_t st) {
+  if (njobs <= 0 || njobs > WG_MAXJOBS || !dy || !x || !dw || !M || !N || !Kw || !ws) return VQA_EARG;
+  static const int nostage = getenv("VQA_WGRAD_NOSTAGE") ? atoi(getenv("VQA_WGRAD_NOSTAGE")) : 0;
+  WgradGroup g; ReduceGroup r;
+  g.n = r.n = njobs; g.blk0[0] = r.blk0[0] = 0;
+  long long off = 0;
+  for (int j = 0; j < njobs; ++j) {
+    WgradPlan pl;
+    if (!dy[j] || !x[j] || !dw[j] || !wgrad_group_plan(dtype, M[j], N[j], Kw[j], &pl)) return VQA_EARG;
+    if (off + pl.ws_floats > ws_floats) return VQA_EARG;
+    WgradParams& p = g.p[j];
+    p.dy = dy[j]; p.x = x[j]; p.dw = dw[j]; p.ws = ws + off; p.M = M[j]; p.N = N[j]; p.Kw = Kw[j];
+    p.B = M[j]; p.H = 1; p.W = 1; p.C = Kw[j]; p.Ho = 1; p.Wo = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+    p.chunk = pl.chunk; p.dbg_noatomic = nostage | (pl.xcd_order ? 0 : 2);
+    const size_t es = dtype ? 2 : 4;
+    p.dy_bytes = (unsigned)((size_t)M[j] * N[j] * es); p.x_bytes = (unsigned)((size_t)M[j] * Kw[j] * es);
+    p.mul_howo = 1ull << 40; p.mul_wo = 1ull << 40;
+    g.gx[j] = ((N[j] + 127) / 128) * ((Kw[j] + 127) / 128); g.gy[j] = pl.nsplit;
+    g.blk0[j + 1] = g.blk0[j] + g.gx[j] * pl.nsplit;
+    r.ws[j] = ws + off; r.dw[j] = dw[j]; r.nsplit[j] = pl.nsplit; r.total4[j] = (unsigned)((size_t)N[j] * Kw[j] / 4);
+    r.blk0[j + 1] = r.blk0[j] + (int)((r.total4[j] + 255) / 256);
+    off += pl.ws_floats;
+  }
+  return dtype ? launch_wgrad_group<bf16_t>(g, r, st) : launch_wgrad_group<float>(g, r, st);
 }
 
 // dw[i] += sum_{s < nslabs} ws[s][i], i < n (n % 4 == 0), slabs added in index order: the second pass of every deterministic

@@ -47,6 +47,8 @@ class HipEngine:
         # +0.5 ms of igemm time for 0.4 ms of reduce passes saved at B=512), so it is an opt-in measurement switch
         self.fuse_bn_reduce = os.environ.get("VQA_BNRED", "0") == "1"
         self._deferred = []
+        self._wgq = []
+        self.group_wgrad = os.environ.get("VQA_WGRAD_GROUP", "1") != "0"
         self._stem_fcoef = None
         self.fold_eval = True                     # inference (eval, no tape): Conv+BN folded, BN never runs as its own pass
         self._fold = None                         # (key, table, nd, blocks, wbuf, bbuf, views)
@@ -241,7 +243,7 @@ class HipEngine:
         Kin = e0.shape[1]
         N = sum(self.E[w].shape[0] for w in wnames)
         M = dz.shape[0]
-        K.wgrad(dz, x_in, G[e0.offset: e0.offset + N * Kin].view(N, Kin), M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype)
+        self._wgrad_linear(dz, x_in, G[e0.offset: e0.offset + N * Kin].view(N, Kin), M, N, Kin)
         wt = self._packT(wnames[0] + ".multiT%d" % len(wnames), [(e0.offset, N, 1, Kin, 0, False)], Kin, N)
         dx, _, _ = K.igemm(dz, wt, M, Kin, N, K.linear_geom(M, N), dtype=self.dtype, addend=addend)
         return dx
@@ -250,6 +252,25 @@ class HipEngine:
         es = [self.E[w] for w in wnames]
         return all(es[i].offset + es[i].numel == es[i + 1].offset and es[i].shape[1] == es[0].shape[1] for i in range(len(es) - 1)) \
             and all(e.shape[0] % 8 == 0 for e in es)
+
+    # ---- token-side Linear weight gradients are collected and launched up to 8 at a time (vqa_wgrad_group): each is a 40-160
+    #      workgroup, latency-bound launch on its own.  The queue is flushed on the stream that produced its operands (when it is
+    #      full, before a gradient segment is reported, before the stream context changes) and holds references to dz / x until then.
+    def _wgrad_linear(self, dz, x_in, dw, M, N, Kin):
+        if self.group_wgrad and K.wgrad_group_ok(self.dtype, M, N, Kin):
+            self._wgq.append((dz, x_in, dw, M, N, Kin))
+            if len(self._wgq) == 8:
+                self._flush_wgq()
+        else:
+            K.wgrad(dz, x_in, dw, M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype)
+
+    def _flush_wgq(self):
+        q, self._wgq = self._wgq, []
+        if len(q) == 1:
+            dz, x_in, dw, M, N, Kin = q[0]
+            K.wgrad(dz, x_in, dw, M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype)
+        elif q:
+            K.wgrad_group(q, dtype=self.dtype)
 
     def _lin_bwd(self, dz, x_in, wname, G, need_dx=True, addend=None):
         """dW += dz^T x ; returns dx = dz W (+ addend)."""
@@ -269,7 +290,7 @@ class HipEngine:
             wp[:N, 0] = LY.mat_of(self.flat, e)
             dx, _, _ = K.igemm(dzp, K.pack_transpose(wp, self.dtype), M, Kin, Np, K.linear_geom(M, Np), dtype=self.dtype, addend=addend)
             return dx
-        K.wgrad(dz, x_in, LY.mat_of(G, e), M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype)
+        self._wgrad_linear(dz, x_in, LY.mat_of(G, e), M, N, Kin)
         if not need_dx:
             return None
         dx, _, _ = K.igemm(dz, self.Wt(wname), M, Kin, N, K.linear_geom(M, N), dtype=self.dtype, addend=addend)
@@ -620,11 +641,13 @@ class HipEngine:
         training = tape["training"]
         B = tape["B"]
         self._deferred = []                       # (a backward that raised must not leak its held-back launches into this one)
+        self._wgq = []
 
         def seg(name):
             """Report a finished gradient segment.  The bucket may be all-reduced once everything enqueued so far on the CURRENT
             stream and on the weight-gradient side stream has run: hand both events to the reducer (its communication stream
             waits for them); the compute streams themselves are NOT joined, so the data-gradient chain is never held back."""
+            self._flush_wgq()                     # queued Linear weight gradients belong to the segment being reported
             if on_segment is None:
                 return
             evs = []

@@ -247,6 +247,43 @@ def wgrad(dy, x, dw, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC):
         PROFILE.append((name, 2.0 * M * N * Kw, e0, e1, (M * N + B * H * W * C) * es + N * Kw * 4))
 
 
+_GROUP_OK = {}
+
+
+def wgrad_group_ok(dtype, M, N, Kw):
+    """True when vqa_wgrad_group takes this Linear weight gradient (the planner's 4-wave 128x128 split kernel)."""
+    key = (dtype, M, N, Kw)
+    v = _GROUP_OK.get(key)
+    if v is None:
+        import ctypes as C_
+        one = lambda a: (C_.c_int * 1)(a)
+        v = _GROUP_OK[key] = L.count("vqa_wgrad_group_ws", dt(dtype), 1, one(M), one(N), one(Kw)) > 0
+    return v
+
+
+def wgrad_group(jobs, *, dtype):
+    """jobs: up to 8 tuples (dy [M][N], x [M][Kw], dw fp32 [N][Kw] (+=), M, N, Kw) -> one launch + one fixed-order reduce launch;
+    every dw is bit-identical to its own wgrad() call."""
+    import ctypes as C_
+    n = len(jobs)
+    VP, IA = C_.c_void_p * n, C_.c_int * n
+    dy, x, dw = VP(*[j[0].data_ptr() for j in jobs]), VP(*[j[1].data_ptr() for j in jobs]), VP(*[j[2].data_ptr() for j in jobs])
+    Ms, Ns, Ks = IA(*[j[3] for j in jobs]), IA(*[j[4] for j in jobs]), IA(*[j[5] for j in jobs])
+    wsf = L.count("vqa_wgrad_group_ws", dt(dtype), n, Ms, Ns, Ks)
+    if wsf <= 0:
+        raise RuntimeError("wgrad_group: a job does not qualify (check wgrad_group_ok first)")
+    ws = torch.empty(wsf, device=jobs[0][0].device, dtype=torch.float32)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_wgrad_group", dt(dtype), n, dy, x, dw, Ms, Ns, Ks, ptr(ws), wsf)
+    if PROFILE is not None:
+        e1.record()
+        es = 2 if dtype == torch.bfloat16 else 4
+        PROFILE.append((f"wgrad_group_kernel<{_tname(dtype)}, 128, 128, 0>", sum(2.0 * j[3] * j[4] * j[5] for j in jobs), e0, e1,
+                        sum((j[3] * j[4] + j[3] * j[5]) * es + j[4] * j[5] * 4 for j in jobs)))
+
+
 def linear_geom(M, K):
     return (M, 1, 1, K, 1, 1, 1, 1, 1, 0)
 
