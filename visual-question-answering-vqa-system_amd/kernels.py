@@ -118,7 +118,7 @@ def wgrad3x3_c64(x, dy, dw, B, H, W):
     call("vqa_wgrad3x3_c64", ptr(x), ptr(dy), ptr(dw), B, H, W, ptr(ws), wsf)
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("wgrad3x3_c64_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
+        PROFILE.append(("wgrad3x3_c64", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))   # prefix of both kernels (4-wave / 8-wave DMA)
 
 
 def dgrad_s2(dy, dyd, wt, B, H, W, C, Ho, Wo, N, R, pad, *, dtype):
