@@ -219,7 +219,7 @@ def test_grouped_linear_weight_gradients_equal_single_launches():
     T = torch.bfloat16
     g = torch.Generator().manual_seed(77)
     shapes = [(10240, 768, 256), (10240, 256, 256), (10240, 1024, 256), (10240, 256, 1024), (25088, 512, 256), (25088, 256, 512),
-              (10240, 256, 256), (512 * 20, 256, 256)]
+              (512, 1000, 256), (512, 256, 512)]                       # the last two: single split (no slab, no reduce blocks), head shapes
     jobs, singles, refs = [], [], []
     for M, N, Kw in shapes:
         assert K.wgrad_group_ok(T, M, N, Kw), (M, N, Kw)
@@ -239,7 +239,10 @@ def test_grouped_linear_weight_gradients_equal_single_launches():
         assert torch.equal(dw_g, dw_s), (M, N, Kw)
         ref = dy.float().t() @ x.float() + 0.5
         assert float((dw_g.cpu() - ref).abs().max() / ref.abs().max()) < 2e-3, (M, N, Kw)
-    assert not K.wgrad_group_ok(T, 512, 1000, 256)                         # one split: goes through vqa_wgrad
-    # two jobs, and the engine's fallback for a single job
-    K.wgrad_group(jobs[:2], dtype=T)
+    assert not K.wgrad_group_ok(T, 512, 1001, 256)                         # N % 8 != 0: goes through the padded single-launch path
+    # a group of single-split jobs only (no workspace at all)
+    dw2 = [torch.zeros_like(j[2]) for j in jobs[6:]]
+    K.wgrad_group([(j[0], j[1], d, j[3], j[4], j[5]) for j, d in zip(jobs[6:], dw2)], dtype=T)
     torch.cuda.synchronize()
+    for j, d in zip(jobs[6:], dw2):
+        assert float((d - (j[2] - 0.5)).abs().max()) < 1e-5 * float(j[2].abs().max())

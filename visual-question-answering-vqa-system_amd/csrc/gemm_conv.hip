@@ -1505,7 +1505,7 @@ static int launch_wgrad_group(const WgradGroup& g, const ReduceGroup& r, hipStre
     attr_set = true;
   }
   hipLaunchKernelGGL((wgrad_group_kernel<T, 128, 128, LOADER_NHWC>), dim3(g.blk0[g.n]), dim3(256), SMEM, st, g);
-  hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(r.blk0[r.n]), dim3(256), 0, st, r);
+  if (r.blk0[r.n] > 0) hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(r.blk0[r.n]), dim3(256), 0, st, r);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }
@@ -1789,7 +1789,8 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
 static bool wgrad_group_plan(int dtype, int M, int N, int Kw, WgradPlan* pl) {
   if (M <= 0 || N <= 0 || Kw <= 0 || (N % (dtype ? 8 : 4)) || (Kw % (dtype ? 8 : 4))) return false;
   *pl = wgrad_plan(dtype, LOADER_NHWC, M, N, Kw, M, 1, 1, Kw, 1, 1, true);
-  return pl->kind == 0 && pl->tn == 128 && pl->tk == 128 && pl->ws_floats > 0 && (pl->ws_floats % 4) == 0 &&
+  // (a single split needs no slab: one += per element, already a fixed order)
+  return pl->kind == 0 && pl->tn == 128 && pl->tk == 128 && (pl->ws_floats > 0 || pl->nsplit == 1) && (pl->ws_floats % 4) == 0 &&
          (size_t)M * N * (dtype ? 2 : 4) < 0x7fffffffull && (size_t)M * Kw * (dtype ? 2 : 4) < 0x7fffffffull && (long)M < (1l << 23);
 }
 long long vqa_wgrad_group_ws(int dtype, int njobs, const int* M, const int* N, const int* Kw) {
@@ -1800,7 +1801,7 @@ long long vqa_wgrad_group_ws(int dtype, int njobs, const int* M, const int* N, c
 }
 int vqa_wgrad_group(int dtype, int njobs, const void* const* dy, const void* const* x, float* const* dw, const int* M, const int* N,
                     const int* Kw, float* ws, long long ws_floats, hipStream_t st) {
-  if (njobs <= 0 || njobs > WG_MAXJOBS || !dy || !x || !dw || !M || !N || !Kw || !ws) return VQA_EARG;
+  if (njobs <= 0 || njobs > WG_MAXJOBS || !dy || !x || !dw || !M || !N || !Kw) return VQA_EARG;
   static const int nostage = getenv("VQA_WGRAD_NOSTAGE") ? atoi(getenv("VQA_WGRAD_NOSTAGE")) : 0;
   WgradGroup g; ReduceGroup r;
   g.n = r.n = njobs; g.blk0[0] = r.blk0[0] = 0;
@@ -1808,9 +1809,9 @@ int vqa_wgrad_group(int dtype, int njobs, const void* const* dy, const void* con
   for (int j = 0; j < njobs; ++j) {
     WgradPlan pl;
     if (!dy[j] || !x[j] || !dw[j] || !wgrad_group_plan(dtype, M[j], N[j], Kw[j], &pl)) return VQA_EARG;
-    if (off + pl.ws_floats > ws_floats) return VQA_EARG;
+    if (pl.ws_floats > 0 && (!ws || off + pl.ws_floats > ws_floats)) return VQA_EARG;
     WgradParams& p = g.p[j];
-    p.dy = dy[j]; p.x = x[j]; p.dw = dw[j]; p.ws = ws + off; p.M = M[j]; p.N = N[j]; p.Kw = Kw[j];
+    p.dy = dy[j]; p.x = x[j]; p.dw = dw[j]; p.ws = pl.ws_floats > 0 ? ws + off : nullptr; p.M = M[j]; p.N = N[j]; p.Kw = Kw[j];
     p.B = M[j]; p.H = 1; p.W = 1; p.C = Kw[j]; p.Ho = 1; p.Wo = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
     p.chunk = pl.chunk; p.dbg_noatomic = nostage | (pl.xcd_order ? 0 : 2);
     const size_t es = dtype ? 2 : 4;
@@ -1818,8 +1819,8 @@ int vqa_wgrad_group(int dtype, int njobs, const void* const* dy, const void* con
     p.mul_howo = 1ull << 40; p.mul_wo = 1ull << 40;
     g.gx[j] = ((N[j] + 127) / 128) * ((Kw[j] + 127) / 128); g.gy[j] = pl.nsplit;
     g.blk0[j + 1] = g.blk0[j] + g.gx[j] * pl.nsplit;
-    r.ws[j] = ws + off; r.dw[j] = dw[j]; r.nsplit[j] = pl.nsplit; r.total4[j] = (unsigned)((size_t)N[j] * Kw[j] / 4);
-    r.blk0[j + 1] = r.blk0[j] + (int)((r.total4[j] + 255) / 256);
+    r.ws[j] = p.ws; r.dw[j] = dw[j]; r.nsplit[j] = pl.nsplit; r.total4[j] = p.ws ? (unsigned)((size_t)N[j] * Kw[j] / 4) : 0u;
+    r.blk0[j + 1] = r.blk0[j] + (int)((r.total4[j] + 255) / 256);      // a single-split job has no slab and no reduce blocks
     off += pl.ws_floats;
   }
   return dtype ? launch_wgrad_group<bf16_t>(g, r, st) : launch_wgrad_group<float>(g, r, st);

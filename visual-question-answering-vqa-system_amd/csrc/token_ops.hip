@@ -840,7 +840,8 @@ static BiasBwdGeom bias_bwd_geom(int dtype, int M, int N) {
   g.vec = N % VEC == 0 && M > 0 && (256 % (N / VEC < 256 ? N / VEC : 256)) == 0;
   if (g.vec) {
     const int cvs = N / VEC, gpb = cvs < 256 ? cvs : 256, lanes_r = 256 / gpb;
-    int gy = (M + 16 * lanes_r - 1) / (16 * lanes_r);        // ~16 row passes per block; <= 1024 blocks in y
+    int gy = (M + 4 * lanes_r - 1) / (4 * lanes_r);          // ~4 row passes per block (16 left a 10 240-row tensor with 80 latency-bound
+                                                             // workgroups: 14 us for 5 MB); <= 1024 blocks in y
     if (gy > 1024) gy = 1024;
     if (gy < 1) gy = 1;
     g.gpb = gpb; g.rows_per = (M + gy - 1) / gy;

@@ -268,9 +268,9 @@ class HipEngine:
         q, self._wgq = self._wgq, []
         if len(q) == 1:
             dz, x_in, dw, M, N, Kin = q[0]
-            K.wgrad(dz, x_in, dw, M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype)
-        elif q:
-            K.wgrad_group(q, dtype=self.dtype)
+            self._off_path([dz, x_in], lambda: K.wgrad(dz, x_in, dw, M, N, Kin, K.linear_geom(M, Kin), dtype=self.dtype))
+        elif q:                                   # side outputs: off the data-gradient chain (second side stream, like the conv dW)
+            self._off_path([t for j in q for t in (j[0], j[1])], lambda: K.wgrad_group(q, dtype=self.dtype))
 
     def _lin_bwd(self, dz, x_in, wname, G, need_dx=True, addend=None):
         """dW += dz^T x ; returns dx = dz W (+ addend)."""

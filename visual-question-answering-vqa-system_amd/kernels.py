@@ -257,7 +257,7 @@ def wgrad_group_ok(dtype, M, N, Kw):
     if v is None:
         import ctypes as C_
         one = lambda a: (C_.c_int * 1)(a)
-        v = _GROUP_OK[key] = L.count("vqa_wgrad_group_ws", dt(dtype), 1, one(M), one(N), one(Kw)) > 0
+        v = _GROUP_OK[key] = L.count("vqa_wgrad_group_ws", dt(dtype), 1, one(M), one(N), one(Kw)) >= 0
     return v
 
 
@@ -270,9 +270,9 @@ def wgrad_group(jobs, *, dtype):
     dy, x, dw = VP(*[j[0].data_ptr() for j in jobs]), VP(*[j[1].data_ptr() for j in jobs]), VP(*[j[2].data_ptr() for j in jobs])
     Ms, Ns, Ks = IA(*[j[3] for j in jobs]), IA(*[j[4] for j in jobs]), IA(*[j[5] for j in jobs])
     wsf = L.count("vqa_wgrad_group_ws", dt(dtype), n, Ms, Ns, Ks)
-    if wsf <= 0:
+    if wsf < 0:
         raise RuntimeError("wgrad_group: a job does not qualify (check wgrad_group_ok first)")
-    ws = torch.empty(wsf, device=jobs[0][0].device, dtype=torch.float32)
+    ws = torch.empty(wsf, device=jobs[0][0].device, dtype=torch.float32) if wsf else None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
