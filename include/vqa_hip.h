@@ -152,7 +152,11 @@ int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
 long long vqa_layernorm_bwd_ws(int dtype, int rows, int D, int period /* 0 when dadd == NULL */);
 int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* gamma, const float* mean_rstd, const void* addend,
                       void* dx, float* dgamma, float* dbeta, int rows, int D, float p, unsigned long long seed, float* dadd,
-                      int period, float* ws, hipStream_t stream);
+                      int period, float* ws, int defer_fold /* 1: skip the fold launch(es), the caller runs vqa_fold_group later */,
+                      hipStream_t stream);
+/* folds of a deferred call: returns their number, 5 values per fold in out[10]: {ws offset (floats), rows, row stride, columns, n0};
+   fold 0 -> (dgamma | dbeta) split at n0 = D, fold 1 (position-embedding sum) -> dadd */
+int vqa_layernorm_bwd_folds(int dtype, int rows, int D, int period, long long* out);
 /* softmax(QK^T/sqrt(hd) [keys with kmask==0 -> -inf]) (dropout) V, one wave per (batch, head)
  * (models/text_encoder.py:237-258, models/cross_attention.py:176-198); probs = softmax before dropout [B][H][Lq][Lk] */
 int vqa_attention_fwd(int dtype, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const float* kmask,
@@ -182,7 +186,11 @@ int vqa_add(int dtype, const void* a, const void* b, void* out, long long n, hip
 /* gradient at the pre-activation of linear(+bias)(+ReLU)(+dropout); dbias += column sums */
 long long vqa_bias_act_bwd_ws(int dtype, int M, int N);
 int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, float* dbias, int M, int N, float p,
-                     unsigned long long seed, float* ws, hipStream_t stream);
+                     unsigned long long seed, float* ws, int defer_fold, hipStream_t stream);
+int vqa_bias_act_bwd_fold_rows(int dtype, int M, int N);   /* deferred fold: {offset 0, this many rows, stride N, N columns, n0 = N} -> dbias */
+/* the deferred folds of any number of calls in one launch per 48 jobs: dst0_j[c] (c < n0_j) / dst1_j[c - n0_j] += sum_r part_j[r*stride_j + c] */
+int vqa_fold_group(int njobs, const float* const* part, const int* nrows, const long long* stride, const int* ncols, float* const* dst0,
+                   const int* n0, float* const* dst1, hipStream_t stream);
 /* nn.CrossEntropyLoss() mean (training/train.py:120): loss += mean NLL, dlogits = (softmax-onehot)*gscale/B.
    err (device int, may be NULL): += number of rows whose target is outside [0, N) -- the reference raises there; such rows are
    never read out of bounds, they add NaN to the loss and get a NaN gradient row. */

@@ -68,7 +68,7 @@ def test_linear_epilogue_dropout_and_its_backward(p):
     dout = torch.randn(M, N, generator=g).to(DEV)
     dz = torch.empty_like(dout)
     dbias = torch.zeros(N, device=DEV)
-    L.call("vqa_bias_act_bwd", 0, dout.data_ptr(), None, dz.data_ptr(), dbias.data_ptr(), M, N, float(p), 1234, None)
+    L.call("vqa_bias_act_bwd", 0, dout.data_ptr(), None, dz.data_ptr(), dbias.data_ptr(), M, N, float(p), 1234, None, 0)
     torch.cuda.synchronize()
     assert torch.equal(dz != 0, kept & (dout != 0))
     assert torch.allclose(dz[kept], dout[kept] / (1 - p), rtol=1e-6)
@@ -77,7 +77,7 @@ def test_linear_epilogue_dropout_and_its_backward(p):
     r1, _, _ = K.igemm(x, w, M, N, Kin, geom, dtype=torch.float32, bias=b, relu=1, drop_p=p, drop_seed=77)
     rbase, _, _ = K.igemm(x, w, M, N, Kin, geom, dtype=torch.float32, bias=b, relu=1)
     dz2 = torch.empty_like(dout)
-    L.call("vqa_bias_act_bwd", 0, dout.data_ptr(), r1.data_ptr(), dz2.data_ptr(), None, M, N, float(p), 77, None)
+    L.call("vqa_bias_act_bwd", 0, dout.data_ptr(), r1.data_ptr(), dz2.data_ptr(), None, M, N, float(p), 77, None, 0)
     torch.cuda.synchronize()
     pos = rbase > 0
     _rate_ok(int((r1 > 0).sum()), int(pos.sum()), p)

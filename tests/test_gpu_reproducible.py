@@ -73,7 +73,7 @@ def test_bias_gradient_fixed_order(dtype, M, N):
         db = torch.zeros(N, device=DEV)
         dz = torch.empty_like(dd)
         L.call("vqa_bias_act_bwd", L.dt(dtype), dd.data_ptr(), ad.data_ptr(), dz.data_ptr(), db.data_ptr(), M, N, 0.0, 0,
-               ws.data_ptr())
+               ws.data_ptr(), 0)
         res.append((db, dz))
     torch.cuda.synchronize()
     assert float((res[0][0].cpu() - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
@@ -81,9 +81,47 @@ def test_bias_gradient_fixed_order(dtype, M, N):
     assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[2][0], res[0][0])
     # without scratch: float atomics, same value up to rounding order
     db2 = torch.zeros(N, device=DEV)
-    L.call("vqa_bias_act_bwd", L.dt(dtype), dd.data_ptr(), ad.data_ptr(), dz.data_ptr(), db2.data_ptr(), M, N, 0.0, 0, None)
+    L.call("vqa_bias_act_bwd", L.dt(dtype), dd.data_ptr(), ad.data_ptr(), dz.data_ptr(), db2.data_ptr(), M, N, 0.0, 0, None, 0)
     torch.cuda.synchronize()
     assert float((db2 - res[0][0]).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_deferred_folds_equal_immediate_folds():
+    """defer_fold = 1 + one vqa_fold_group launch for several LayerNorm / bias backward calls gives the same bits as each entry's own fold."""
+    L, K = sub("_lib"), sub("kernels")
+    T = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    q, want = [], []
+    for rows, D, period in ((10240, 256, 0), (25088, 256, 49), (512, 256, 0)):
+        x = torch.randn(rows, D, generator=g).to(T).to(DEV)
+        gam, bet = (torch.rand(D, generator=g) + 0.5).to(DEV), torch.randn(D, generator=g).to(DEV)
+        dout = torch.randn(rows, D, generator=g).to(T).to(DEV)
+        _, st = K.layernorm_fwd(x, gam, bet)
+        res = []
+        for fq in (None, q):
+            dgam, dbet = torch.full((D,), 0.25, device=DEV), torch.zeros(D, device=DEV)
+            dpos = torch.zeros(period, D, device=DEV) if period else None
+            K.layernorm_bwd(dout, x, gam, st, dgam, dbet, dadd=dpos, period=max(period, 1), foldq=fq)
+            res.append((dgam, dbet, dpos))
+        want.append(res)
+    for M, N in ((10240, 1024), (512, 1000)):
+        dout = torch.randn(M, N, generator=g).to(T).to(DEV)
+        wsf = K.reduce_ws("vqa_bias_act_bwd_ws", L.dt(T), M, N)
+        res = []
+        for defer in (0, 1):
+            ws, db = torch.empty(wsf, device=DEV), torch.full((N,), -1.0, device=DEV)
+            L.call("vqa_bias_act_bwd", L.dt(T), dout.data_ptr(), None, None, db.data_ptr(), M, N, 0.0, 0, ws.data_ptr(), defer)
+            if defer:
+                q.append((ws, 0, L.count("vqa_bias_act_bwd_fold_rows", L.dt(T), M, N), N, N, db, N, None))
+            res.append((db,))
+        want.append(res)
+    assert len(q) == 3 + 1 + 2
+    K.fold_group(q)
+    torch.cuda.synchronize()
+    for res in want:
+        for a, b in zip(res[0], res[1]):
+            if a is not None:
+                assert torch.equal(a, b) and float(a.abs().max()) > 0
 
 
 def test_cross_entropy_loss_fixed_order():

@@ -62,7 +62,8 @@ SIGNATURES = {
     "vqa_embed_bwd": [I, P, P, P, I, I, I, F, F, ULL, P],
     "vqa_layernorm_fwd": [I, P, P, P, P, P, I, I, F, F, ULL, P, I, P],
     "vqa_layernorm_bwd_ws": [I, I, I, I],
-    "vqa_layernorm_bwd": [I, P, P, P, P, P, P, P, P, I, I, F, ULL, P, I, P, P],
+    "vqa_layernorm_bwd": [I, P, P, P, P, P, P, P, P, I, I, F, ULL, P, I, P, I, P],
+    "vqa_layernorm_bwd_folds": [I, I, I, I, P],
     "vqa_attention_fwd": [I, P, P, P, I, I, I, P, P, P, I, I, I, I, I, I, F, ULL, P],
     "vqa_attention_fwd_mfma": [P, P, P, I, I, I, P, P, P, I, I, I, I, I, I, F, ULL, P],
     "vqa_attention_bwd": [I, P, I, P, P, P, I, I, I, P, P, P, P, I, I, I, I, I, I, I, I, F, ULL, P],
@@ -74,7 +75,9 @@ SIGNATURES = {
     "vqa_gate_bwd": [I, P, P, P, P, P, I, I, P],
     "vqa_add": [I, P, P, P, LL, P],
     "vqa_bias_act_bwd_ws": [I, I, I],
-    "vqa_bias_act_bwd": [I, P, P, P, P, I, I, F, ULL, P, P],
+    "vqa_bias_act_bwd": [I, P, P, P, P, I, I, F, ULL, P, I, P],
+    "vqa_bias_act_bwd_fold_rows": [I, I, I],
+    "vqa_fold_group": [I, P, P, P, P, P, P, P, P],
     "vqa_cross_entropy": [I, P, P, P, P, P, I, I, F, P, P, P],
     "vqa_convert": [I, I, P, P, LL, P],
     "vqa_sumsq": [P, LL, P, P],
@@ -83,7 +86,7 @@ SIGNATURES = {
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P],
 }
 _RET_LL = {"vqa_wgrad_group_ws", "vqa_spatial_bwd_scratch", "vqa_layernorm_bwd_ws", "vqa_bias_act_bwd_ws"}                       # return a size (long long)
-_NO_STATUS = _RET_LL | {"vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
+_NO_STATUS = _RET_LL | {"vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
 
 _lib = None
 

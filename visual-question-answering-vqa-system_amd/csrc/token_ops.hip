@@ -62,6 +62,43 @@ __global__ __launch_bounds__(1024) void fold_rows_kernel(const float* __restrict
 static inline void launch_fold(const float* part, int nrows, size_t stride, int ncols, float* dst0, int n0, float* dst1, hipStream_t st) {
   hipLaunchKernelGGL(fold_rows_kernel, dim3((ncols + 63) / 64), dim3(64, 16), 0, st, part, nrows, stride, ncols, dst0, n0, dst1);
 }
+// Many folds in one launch: the parameter gradients they produce are only read by the optimizer at the end of the step, so the engine
+// queues them (defer_fold = 1 in the producing entries) and folds a whole gradient segment at once instead of paying one tiny launch per
+// LayerNorm / bias on the data-gradient chain.  Same arithmetic per job as fold_rows_kernel (same row groups, same fold order).
+constexpr int FOLD_MAXJOBS = 48;
+struct FoldJob { const float* part; float* dst0; float* dst1; int nrows, ncols, n0; unsigned stride; };
+struct FoldGroup { FoldJob j[FOLD_MAXJOBS]; int blk0[FOLD_MAXJOBS + 1]; int n; };
+__global__ __launch_bounds__(1024) void fold_group_kernel(FoldGroup g) {
+  int lo = 0, hi = g.n - 1;                                  // last job whose first block <= blockIdx.x (uniform)
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (g.blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+  const FoldJob& job = g.j[lo];
+  const float* __restrict__ part = job.part;
+  const int nrows = job.nrows, ncols = job.ncols;
+  const size_t stride = job.stride;
+  const int c = ((int)blockIdx.x - g.blk0[lo]) * 64 + threadIdx.x, rg = threadIdx.y;
+  const int per = (nrows + 15) / 16, r0 = rg * per, r1 = min(nrows, r0 + per);
+  float t = 0.f;
+  if (c < ncols) {
+    int r = r0;
+    for (; r + 16 <= r1; r += 16) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = part[(size_t)(r + i) * stride + c];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += v[i];
+    }
+    for (; r < r1; ++r) t += part[(size_t)r * stride + c];
+  }
+  __shared__ float sh[16][64];
+  sh[rg][threadIdx.x] = t;
+  __syncthreads();
+  if (rg == 0 && c < ncols) {
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a += sh[q][threadIdx.x];
+    if (c < job.n0) job.dst0[c] += a; else job.dst1[c - job.n0] += a;
+  }
+}
 
 // Gradient of the embedding table WITHOUT atomics: a workgroup owns 16 consecutive table rows, walks the id list in row order
 // (1024 ids per pass, hits compacted in order through LDS) and adds the matching rows of dout to LDS accumulators in that order
@@ -758,10 +795,21 @@ long long vqa_layernorm_bwd_ws(int dtype, int rows, int D, int period) {
 }
 // ws: scratch of vqa_layernorm_bwd_ws floats -> dgamma / dbeta / dadd are summed in a fixed order (bit-reproducible);
 // nullptr -> float atomics (same values up to rounding order).
+// Fold descriptors of vqa_layernorm_bwd for a caller that defers the folds (defer_fold = 1): returns the number of folds (1, or 2 with a
+// position-embedding sum) and writes 5 values per fold to out: {offset into ws (floats), rows, row stride, columns, n0}; fold 0 targets
+// (dgamma | dbeta) split at column n0 = D, fold 1 targets dadd.
+int vqa_layernorm_bwd_folds(int dtype, int rows, int D, int period, long long* out) {
+  if (D > 512 || rows <= 0 || !out) return 0;
+  const LnBwdGeom g = ln_bwd_geom(dtype, rows, D, period);
+  out[0] = 0; out[1] = g.nb; out[2] = 2 * D; out[3] = 2 * D; out[4] = D;
+  if (!g.colsum) return 1;
+  out[5] = (long long)g.nb * 2 * D; out[6] = g.gy; out[7] = (long long)g.N; out[8] = (long long)g.N; out[9] = (long long)g.N;
+  return 2;
+}
 int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* gamma, const float* stats, const void* addend, void* dx,
                       float* dgamma, float* dbeta, int rows, int D, float p, unsigned long long seed, float* dadd, int period,
-                      float* ws, hipStream_t st) {
-  if (D > 512 || rows <= 0) return VQA_EARG;
+                      float* ws, int defer_fold, hipStream_t st) {
+  if (D > 512 || rows <= 0 || (defer_fold && !ws)) return VQA_EARG;
   const LnBwdGeom g = ln_bwd_geom(dtype, rows, D, dadd ? period : 0);
   float* part_ln = ws;
   float* part_cs = ws ? ws + (size_t)g.nb * 2 * D : nullptr;
@@ -771,7 +819,7 @@ int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* g
     dim3 grid(g.gx, g.gy);
     DT(hipLaunchKernelGGL(colsum_rows_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, dadd, Bb, g.N, part_cs),
        hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, dadd, Bb, g.N, part_cs));
-    if (part_cs) launch_fold(part_cs, (int)g.gy, g.N, (int)g.N, dadd, (int)g.N, nullptr, st);
+    if (part_cs && !defer_fold) launch_fold(part_cs, (int)g.gy, g.N, (int)g.N, dadd, (int)g.N, nullptr, st);
     dadd = nullptr;
   }
   if (dtype && D % 8 == 0) {                               // vectorised bf16 path, >= 4 rows per wave, at most one workgroup per CU
@@ -781,7 +829,7 @@ int vqa_layernorm_bwd(int dtype, const void* dout, const void* x, const float* g
     DT(hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(g.nb), dim3(256), 0, st, (const float*)dout, (const float*)x, gamma, stats, (const float*)addend, (float*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period, part_ln),
        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(g.nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, stats, (const bf16_t*)addend, (bf16_t*)dx, dgamma, dbeta, rows, D, p, seed, dadd, period, part_ln));
   }
-  if (part_ln) launch_fold(part_ln, g.nb, (size_t)2 * D, 2 * D, dgamma, D, dbeta, st);
+  if (part_ln && !defer_fold) launch_fold(part_ln, g.nb, (size_t)2 * D, 2 * D, dgamma, D, dbeta, st);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_attention_fwd(int dtype, const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const float* kmask, float* probs,
@@ -859,9 +907,14 @@ long long vqa_bias_act_bwd_ws(int dtype, int M, int N) {
   return (long long)g.grid.y * N;
 }
 // ws: vqa_bias_act_bwd_ws floats -> dbias summed in a fixed order (bit-reproducible); nullptr -> float atomics on dbias.
+// rows of the partial slab (= rows of the deferred fold {offset 0, rows, stride N, N columns, n0 = N} into dbias)
+int vqa_bias_act_bwd_fold_rows(int dtype, int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (int)bias_bwd_geom(dtype, M, N).grid.y;
+}
 int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, float* dbias, int M, int N, float p, unsigned long long seed,
-                     float* ws, hipStream_t st) {
-  if (M <= 0 || N <= 0) return VQA_EARG;
+                     float* ws, int defer_fold, hipStream_t st) {
+  if (M <= 0 || N <= 0 || (defer_fold && !ws)) return VQA_EARG;
   const BiasBwdGeom g = bias_bwd_geom(dtype, M, N);
   if (g.vec) {
     DT(hipLaunchKernelGGL(bias_act_bwd_vec_kernel<float>, g.grid, dim3(256), 0, st, (const float*)dout, (const float*)outact, (float*)dz, dbias, M, N, p, seed, g.rows_per, ws),
@@ -870,7 +923,27 @@ int vqa_bias_act_bwd(int dtype, const void* dout, const void* outact, void* dz, 
     DT(hipLaunchKernelGGL(bias_act_bwd_kernel<float>, g.grid, dim3(256), 0, st, (const float*)dout, (const float*)outact, (float*)dz, dbias, M, N, 0, p, seed, ws),
        hipLaunchKernelGGL(bias_act_bwd_kernel<bf16_t>, g.grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)outact, (bf16_t*)dz, dbias, M, N, 0, p, seed, ws));
   }
-  if (ws && dbias) launch_fold(ws, (int)g.grid.y, (size_t)N, N, dbias, N, nullptr, st);
+  if (ws && dbias && !defer_fold) launch_fold(ws, (int)g.grid.y, (size_t)N, N, dbias, N, nullptr, st);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+// dst0_j[c] (c < n0_j) / dst1_j[c - n0_j] += sum over rows r < nrows_j of part_j[r * stride_j + c], rows in index order -- the deferred folds of
+// any number of vqa_layernorm_bwd / vqa_bias_act_bwd calls (defer_fold = 1) in ceil(njobs / 48) launches.
+int vqa_fold_group(int njobs, const float* const* part, const int* nrows, const long long* stride, const int* ncols, float* const* dst0,
+                   const int* n0, float* const* dst1, hipStream_t st) {
+  if (njobs <= 0 || !part || !nrows || !stride || !ncols || !dst0 || !n0 || !dst1) return VQA_EARG;
+  for (int base = 0; base < njobs; base += FOLD_MAXJOBS) {
+    FoldGroup g;
+    g.n = njobs - base < FOLD_MAXJOBS ? njobs - base : FOLD_MAXJOBS;
+    g.blk0[0] = 0;
+    for (int q = 0; q < g.n; ++q) {
+      const int j = base + q;
+      if (!part[j] || !dst0[j] || nrows[j] <= 0 || ncols[j] <= 0 || stride[j] <= 0 || stride[j] > 0xffffffffll || (n0[j] < ncols[j] && !dst1[j]))
+        return VQA_EARG;
+      g.j[q] = FoldJob{part[j], dst0[j], dst1[j], nrows[j], ncols[j], n0[j], (unsigned)stride[j]};
+      g.blk0[q + 1] = g.blk0[q] + (ncols[j] + 63) / 64;
+    }
+    hipLaunchKernelGGL(fold_group_kernel, dim3(g.blk0[g.n]), dim3(64, 16), 0, st, g);
+  }
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // ws (B floats or nullptr): the per-row loss terms are summed in row order by a second launch (bit-reproducible); nullptr -> one

@@ -49,6 +49,8 @@ class HipEngine:
         self._deferred = []
         self._wgq = []
         self.group_wgrad = os.environ.get("VQA_WGRAD_GROUP", "1") != "0"
+        self._foldq = []                          # deferred folds of the LayerNorm / bias parameter gradients (K.fold_group at segment end)
+        self.defer_folds = os.environ.get("VQA_DEFER_FOLDS", "1") != "0"
         self._stem_fcoef = None
         self.fold_eval = True                     # inference (eval, no tape): Conv+BN folded, BN never runs as its own pass
         self._fold = None                         # (key, table, nd, blocks, wbuf, bbuf, views)
@@ -309,7 +311,10 @@ class HipEngine:
             ws = None
             if dbias is not None:          # fixed-order column sums (bit-reproducible): per-workgroup rows + index-order fold
                 ws = torch.empty((K.reduce_ws("vqa_bias_act_bwd_ws", dt(dout), M, N),), device=dout.device, dtype=torch.float32)
-            call("vqa_bias_act_bwd", dt(dout), ptr(dout), ptr(outact), ptr(dz), ptr(dbias), M, N, float(p), int(seed), ptr(ws))
+            defer = int(ws is not None and self.defer_folds)
+            call("vqa_bias_act_bwd", dt(dout), ptr(dout), ptr(outact), ptr(dz), ptr(dbias), M, N, float(p), int(seed), ptr(ws), defer)
+            if defer:                      # the bias gradient is only read by the optimizer: fold it with the rest of the segment
+                self._foldq.append((ws, 0, K.L.count("vqa_bias_act_bwd_fold_rows", dt(dout), M, N), N, N, dbias, N, None))
         return dz if need_dz else dout
 
     def _ln(self, x, prefix, p=0.0, seed=0, addrow=None, period=1):
@@ -319,7 +324,8 @@ class HipEngine:
     def _ln_bwd(self, dout, x, prefix, stats, G, addend=None, p=0.0, seed=0, dadd=None, period=1):
         eg, eb = self.E[prefix + ".weight"], self.E[prefix + ".bias"]
         return K.layernorm_bwd(dout, x, self.P(prefix + ".weight"), stats, G[eg.offset: eg.offset + eg.numel],
-                               G[eb.offset: eb.offset + eb.numel], addend=addend, drop_p=p, seed=seed, dadd=dadd, period=period)
+                               G[eb.offset: eb.offset + eb.numel], addend=addend, drop_p=p, seed=seed, dadd=dadd, period=period,
+                               foldq=self._foldq if self.defer_folds else None)
 
     def _off_path(self, tensors, fn, defer=False):
         """Run fn (a weight-gradient launch) on the second side stream: it only needs `tensors` (already produced on the
@@ -642,12 +648,15 @@ class HipEngine:
         B = tape["B"]
         self._deferred = []                       # (a backward that raised must not leak its held-back launches into this one)
         self._wgq = []
+        self._foldq = []
 
         def seg(name):
             """Report a finished gradient segment.  The bucket may be all-reduced once everything enqueued so far on the CURRENT
             stream and on the weight-gradient side stream has run: hand both events to the reducer (its communication stream
             waits for them); the compute streams themselves are NOT joined, so the data-gradient chain is never held back."""
             self._flush_wgq()                     # queued Linear weight gradients belong to the segment being reported
+            fq, self._foldq = self._foldq, []     # so do the parameter-gradient folds queued on this stream since the last segment
+            K.fold_group(fq)
             if on_segment is None:
                 return
             evs = []
@@ -756,6 +765,7 @@ class HipEngine:
         # ---- stem
         self._stem_bwd(tape, dxc, G, training, after_reduce=lambda: (self._flush_deferred_and_report(seg)))
         seg("image_encoder.stem")
+        self._flush_wgq(); K.fold_group(self._foldq); self._foldq = []      # (both queues are empty here: every token-side section ends in seg())
         self._join_off_path()
         if use_side:
             main.wait_event(ev_tb)

@@ -358,15 +358,51 @@ def reduce_ws(name, *args):
     return v
 
 
-def layernorm_bwd(dout, x, gamma, stats, dgamma, dbeta, *, addend=None, drop_p=0.0, seed=0, dadd=None, period=1, fixed_order=True):
+_FOLD_DESC = {}
+
+
+def ln_bwd_folds(dtype, rows, D, period):
+    """[(ws offset, rows, stride, columns, n0), ...] of a deferred vqa_layernorm_bwd (cached by shape)."""
+    key = (dtype, rows, D, period)
+    v = _FOLD_DESC.get(key)
+    if v is None:
+        import ctypes as C_
+        out = (C_.c_longlong * 10)()
+        n = L.count("vqa_layernorm_bwd_folds", dt(dtype), rows, D, period, out)
+        v = _FOLD_DESC[key] = [tuple(int(out[5 * i + k]) for k in range(5)) for i in range(n)]
+    return v
+
+
+def fold_group(jobs):
+    """jobs: (part tensor, element offset, rows, stride, columns, dst0, n0, dst1 | None): the deferred folds of LayerNorm / bias backward
+    calls, one launch per 48 jobs; each job keeps its scratch tensor alive until here."""
+    import ctypes as C_
+    n = len(jobs)
+    if not n:
+        return
+    VP, IA, LA = C_.c_void_p * n, C_.c_int * n, C_.c_longlong * n
+    call("vqa_fold_group", n, VP(*[j[0].data_ptr() + 4 * j[1] for j in jobs]), IA(*[j[2] for j in jobs]), LA(*[j[3] for j in jobs]),
+         IA(*[j[4] for j in jobs]), VP(*[j[5].data_ptr() for j in jobs]), IA(*[j[6] for j in jobs]),
+         VP(*[(j[7].data_ptr() if j[7] is not None else None) for j in jobs]))
+
+
+def layernorm_bwd(dout, x, gamma, stats, dgamma, dbeta, *, addend=None, drop_p=0.0, seed=0, dadd=None, period=1, fixed_order=True, foldq=None):
     """fixed_order: dgamma / dbeta / dadd are summed through per-workgroup partial rows + an index-order fold (bit-reproducible);
-    False -> float atomics."""
+    False -> float atomics.  foldq (a list): the folds are not launched here but appended as fold_group() jobs."""
     rows, D = x.shape
     dx = torch.empty_like(x)
     ws = None
+    per = period if dadd is not None else 0
     if fixed_order:
-        ws = torch.empty((reduce_ws("vqa_layernorm_bwd_ws", dt(x), rows, D, period if dadd is not None else 0),),
-                         device=x.device, dtype=torch.float32)
+        ws = torch.empty((reduce_ws("vqa_layernorm_bwd_ws", dt(x), rows, D, per),), device=x.device, dtype=torch.float32)
+    defer = int(foldq is not None and ws is not None)
     call("vqa_layernorm_bwd", dt(x), ptr(dout), ptr(x), ptr(gamma), ptr(stats), ptr(addend), ptr(dx), ptr(dgamma), ptr(dbeta),
-         rows, D, float(drop_p), int(seed), ptr(dadd), period, ptr(ws))
+         rows, D, float(drop_p), int(seed), ptr(dadd), period, ptr(ws), defer)
+    if defer:
+        folds = ln_bwd_folds(x.dtype, rows, D, per)
+        off, nr, st, nc, n0 = folds[0]
+        foldq.append((ws, off, nr, st, nc, dgamma, n0, dbeta))
+        if len(folds) > 1:
+            off, nr, st, nc, n0 = folds[1]
+            foldq.append((ws, off, nr, st, nc, dadd, n0, None))
     return dx
