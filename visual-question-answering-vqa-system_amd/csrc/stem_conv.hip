@@ -149,7 +149,8 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                                                          int B, int H, int W, int Ho, int Wo, const bf16_t* __restrict__ dpool,
                                                          const uint8_t* __restrict__ idx, const float* __restrict__ coef,
-                                                         const float* __restrict__ bc, int Hp, int Wp, int nsplit, float* __restrict__ ws) {
+                                                         const float* __restrict__ bc, int Hp, int Wp, int nsplit, float* __restrict__ ws,
+                                                         int dbg /* VQA_STEMW_DBG, measurement only: 1 no pool routing, 2 no im2col slice, 4 no MFMA, 8 no dY staging */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PW = 2 * Wo + 8;
   const int Wh = Wo / nsplit;                                        // pixels per unit: a row is contracted in nsplit pieces so that
@@ -204,13 +205,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       __syncthreads();                                               // patch ready / previous unit's MFMA reads done
       // dy row piece -> LDS (16-byte vectors), im2col slice -> LDS
       const bf16_t* dyr = dy + (((size_t)b * Ho + oh0 + orow) * Wo + px0) * 64;
-      for (int v = tid; v < Wh * 8; v += 256) {
+      for (int v = tid; v < ((dbg & 8) ? 0 : Wh * 8); v += 256) {
         const int px = v >> 3, cv = v & 7;
         u32x4 val = *reinterpret_cast<const u32x4*>(dyr + (size_t)px * 64 + cv * 8);      // dy row, or y row when FUSED
         if (FUSED) {
           Vec16<bf16_t> yy; yy.raw = val;
           float g8[8];
-          stem_route<bf16_t>(dpool, idx, yy, f_sc, f_sh, b, oh0 + orow, px0 + px, cv * 8, 64, Hp, Wp, g8);
+          if (!(dbg & 1)) stem_route<bf16_t>(dpool, idx, yy, f_sc, f_sh, b, oh0 + orow, px0 + px, cv * 8, 64, Hp, Wp, g8);
+          else { for (int j = 0; j < 8; ++j) g8[j] = 0.f; }
           Vec16<bf16_t> o;
 #pragma unroll
           for (int j = 0; j < 8; ++j) o.set(j, f_a[j] * g8[j] + f_b[j] * yy.get(j) + f_c[j]);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[px * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned
         d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
       }
-      if (tid < 240) {                                               // 10 pixels x 24 (c,r) pairs per pass
+      if (tid < 240 && !(dbg & 2)) {                                 // 10 pixels x 24 (c,r) pairs per pass
         const int pair = tid % 24, c = pair / 7, r = pair - c * 7;
         const bf16_t* prow = patch + (c * PRW + 2 * orow + r) * PW + 2 * px0;
         for (int px = tid / 24; px < Wh; px += 10) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       }
       __syncthreads();
       typedef __attribute__((ext_vector_type(8))) short i16x8;
-      for (int ks = 0; ks < MP / 32; ++ks) {
+      for (int ks = 0; ks < ((dbg & 4) ? 0 : MP / 32); ++ks) {
         const bf16_t* yb = Dy + (ks * 32 + 8 * g + q) * LDD + 4 * pp;
         const bf16_t* xb = Acol + (ks * 32 + 8 * g + q) * LDA + wave * 48 + 4 * pp;
         bf16x8 af[4], bfv[3];
@@ -346,7 +348,7 @@ int vqa_stem_wgrad(const float* img, const void* dy, float* dw, int B, int H, in
   int grid = nblocks < cap ? nblocks : cap;
   float* w = (ws && ws_floats >= (long long)grid * 64 * 147) ? ws : nullptr;
   hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)dy, dw, B, H, W, Ho, Wo,
-                     (const bf16_t*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, nsplit, w);
+                     (const bf16_t*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, nsplit, w, 0);
   VQA_LAUNCH_CHECK();
   return w ? vqa_slab_reduce(w, dw, grid, 64 * 147, st) : VQA_OK;
 }
@@ -367,7 +369,7 @@ int vqa_stem_wgrad_fused(const float* img, const void* y, const void* dpool, con
   int grid = nblocks < cap ? nblocks : cap;
   float* w = (ws && ws_floats >= (long long)grid * 64 * 147) ? ws : nullptr;
   hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)y, dw, B, H, W, Ho, Wo,
-                     (const bf16_t*)dpool, idx, coef, bcoef, Hp, Wp, nsplit, w);
+                     (const bf16_t*)dpool, idx, coef, bcoef, Hp, Wp, nsplit, w, getenv("VQA_STEMW_DBG") ? atoi(getenv("VQA_STEMW_DBG")) : 0);
   VQA_LAUNCH_CHECK();
   return w ? vqa_slab_reduce(w, dw, grid, 64 * 147, st) : VQA_OK;
 }
