@@ -7,6 +7,7 @@
 //   masked mean / gate        models/fusion.py:303-320, :160-166
 //   CE / clip / AdamW         training/train.py:120, :204-208, :127-132
 // Rows are tokens ([B*L][D], D contiguous).  One 64-lane wave owns one row / one (batch, head).
+#include <cstdlib>
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -777,7 +778,10 @@ int vqa_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
 struct LnBwdGeom { int nb; bool colsum; unsigned gx, gy; size_t N; };
 static LnBwdGeom ln_bwd_geom(int dtype, int rows, int D, int period) {
   LnBwdGeom g = {0, false, 0, 0, 0};
-  if (dtype && D % 8 == 0) { g.nb = (rows + 31) / 32; if (g.nb > 256) g.nb = 256; }
+  if (dtype && D % 8 == 0) {                                 // 8 waves per block, ~2 rows per wave (4+ rows left 10 240-row tensors latency-bound: 13 us for 15 MB)
+    static const int rpb = getenv("VQA_LN_BWD_ROWS") ? atoi(getenv("VQA_LN_BWD_ROWS")) : 16;
+    g.nb = (rows + rpb - 1) / rpb; if (g.nb > 1024) g.nb = 1024;
+  }
   else g.nb = (rows + 15) / 16 > 2048 ? 2048 : (rows + 15) / 16;
   if (period > 0 && rows % period == 0 && ((size_t)period * D) % (dtype ? 8 : 4) == 0) {
     const int Bb = rows / period;
