@@ -1591,7 +1591,8 @@ static WgradPlan wgrad_plan(int dtype, int loader, int M, int N, int Kw, int B, 
   pl.xcd_order = in_bytes >= 80.0 * dw_bytes;
   long nsplit = (target + tiles - 1) / tiles;
   // token-side GEMMs (M ~ 10^4) are flush-bound unless a split keeps >= ~1000 rows (16 steps) of work
-  const long minchunk = minrows_env ? minrows_env : 1024;
+  // (2048 for the Linears: they are launched 8 per group, ~one round of workgroups per group and half the slab traffic)
+  const long minchunk = minrows_env ? minrows_env : ((!conv && M <= 65536) ? 2048 : 1024);
   const long maxsplit = (M + minchunk - 1) / minchunk;
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit < 1) nsplit = 1;
