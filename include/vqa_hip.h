@@ -66,6 +66,11 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
  * block, input patches by LDS-DMA, weights in registers; stats [vqa_conv3x3_c64p_blocks][2][64] or NULL.  H % 8 == 0, W % 8 == 0. */
 int vqa_conv3x3_c64p_blocks(int B, int H, int W);
 int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, hipStream_t stream);
+/* stage-2 weight gradient (3x3 / 1 / pad 1, 128 -> 128 channels, 28 x 28 maps, bf16; models/cnn_backbone.py:182-187 backward): 8-wave
+   LDS-DMA kernel + fixed-order slab reduce.  vqa_wgrad3x3_c128_blocks: slabs of 128*576 floats the workspace must hold, 0 = shape not
+   supported (the caller uses vqa_wgrad). */
+int vqa_wgrad3x3_c128_blocks(int B, int H, int W);
+int vqa_wgrad3x3_c128(const void* x, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t stream);
 int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw /* [64][576] += */, int B, int H, int W,
                      float* ws /* >= vqa_conv3x3_c64_blocks * 64*576 floats of scratch, or NULL: atomics */, long long ws_floats, hipStream_t stream);
 /* Up to 8 Linear weight gradients dw_j[N_j][K_j] += dy_j[M_j][N_j]^T x_j[M_j][K_j] in ONE launch + ONE fixed-order reduce launch

@@ -240,6 +240,29 @@ def test_conv3x3_c64_patch_kernels(case):
     assert _relerr(dw.cpu(), wr.grad.permute(0, 2, 3, 1).reshape(64, 576)) < 3e-3
 
 
+@pytest.mark.parametrize("B", [1, 3, 40])                                  # 40 images: 280 row blocks > 128 persistent workgroups per half
+def test_wgrad3x3_c128_stage2_kernel(B):
+    """Stage-2 weight gradient (128 -> 128, 28 x 28, bf16): 8-wave LDS-DMA kernel against torch's conv2d weight gradient on the
+    bf16-rounded operands; += semantics; bit-reproducible."""
+    K = sub("kernels")
+    H = W = 28
+    assert K.c128_wgrad_blocks(B, H, W) > 0 and K.c128_wgrad_blocks(B, 14, 14) == 0
+    g = torch.Generator().manual_seed(500 + B)
+    x = _round(torch.randn(B, 128, H, W, generator=g), torch.bfloat16)
+    dy = _round(torch.randn(B, 128, H, W, generator=g) * 0.1, torch.bfloat16)
+    ref = torch.nn.grad.conv2d_weight(x, (128, 128, 3, 3), dy, stride=1, padding=1).permute(0, 2, 3, 1).reshape(128, 1152)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16)
+    xd, dyd = nhwc(x), nhwc(dy)
+    outs = []
+    for rep in range(2):
+        dw = torch.full((128, 1152), 0.25, device=DEV)
+        K.wgrad3x3_c128(xd, dyd, dw, B, H, W)
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert _relerr(outs[0].cpu() - 0.25, ref) < 3e-3
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_pack_transpose_batch_matches_single_launches():
     """The tiled one-launch weight transpose (begin_step) against the per-weight kernel, including taps, flip, a column
     offset inside a wider row, and dimensions that are not multiples of the 32x32 tile."""

@@ -688,6 +688,179 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_c64p_kernel(C64WgradParams p)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient of the stage-2 convs (3x3 / 1, 128 -> 128 channels, 28 x 28), same structure as wgrad3x3_c64p_kernel:
+// the generic split-K tile kernel runs these at 0.72 PFLOP/s (112 splits of 9 tiles, 66 MB of slabs); here a workgroup keeps a
+// 128 (output channels) x 9 taps x 64 (one HALF of the input channels) block of dW in its accumulators for the whole launch
+// (8 waves = 4 input-channel tiles x 2 output-channel halves, 36 accumulators = 144 VGPRs per wave) and walks (image, 4 rows) blocks:
+// the 6 x 30 x 64 slice of X and the 112 x 128 tile of dY arrive by LDS-DMA into a double buffer one block ahead.  Two workgroup
+// populations (input-channel half = blockIdx & 1) of 128 persistent workgroups each.  W = 28 is not a multiple of the 8-pixel DMA
+// piece: the patch rows have a pitch of 34 pixels and the last piece of a row fetches pixels 24..31 with the lanes beyond the image
+// out of range -> zeros, which also writes the right halo column.  dY rows are 256 bytes (the whole bank window), so its transposed
+// reads are made conflict free by XORing the 32-byte slot index with g(p) = (p & 3) | ((p >> 3 & 1) << 2) on the DMA source side.
+// Reads are hand-issued two taps ahead with counted lgkmcnt waits, all addresses precomputed (compile-time geometry).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int C128_W = 28, C128_RB = 4, C128_PW = 34, C128_NPX = C128_RB * C128_W, C128_NKS = 4;
+constexpr int C128_PATCH = (C128_RB + 2) * C128_PW * 128, C128_DY = 128 * 256, C128_BUF = C128_PATCH + C128_DY;
+__device__ __forceinline__ int gsw8(int p) { return (p & 3) | (((p >> 3) & 1) << 2); }
+}
+struct C128WgradParams { const bf16_t* x; const bf16_t* dy; float* ws; int B; unsigned bytes; };
+
+__global__ __launch_bounds__(512, 2) void wgrad3x3_c128p_kernel(C128WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cw = wave & 3, nh = wave >> 2;
+  const int half = blockIdx.x & 1, wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
+  const int nblocks = p.B * (C128_W / C128_RB);
+  const unsigned long long xa = (unsigned long long)p.x, ya = (unsigned long long)p.dy;
+  const i32x4_c64 rsX = {(int)(unsigned)xa, (int)((unsigned)(xa >> 32) & 0xffffu), (int)p.bytes, 0x00020000};
+  const i32x4_c64 rsY = {(int)(unsigned)ya, (int)((unsigned)(ya >> 32) & 0xffffu), (int)p.bytes, 0x00020000};
+
+  // ---- once: left halo column of every patch row and the 16 padding pixel rows of the dY tile (never written by the DMA)
+  for (int i = tid; i < 2 * (C128_RB + 2) * 8; i += 512) {
+    const int chunk = i & 7, prow = (i >> 3) % (C128_RB + 2), buf = (i >> 3) / (C128_RB + 2);
+    *reinterpret_cast<u32x4*>(smem + buf * C128_BUF + (prow * C128_PW) * 128 + chunk * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  for (int i = tid; i < 2 * 16 * 16; i += 512) {
+    const int buf = i >> 8, o = i & 255;
+    *reinterpret_cast<u32x4*>(smem + buf * C128_BUF + C128_PATCH + C128_NPX * 256 + o * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  // ---- DMA plan: 24 x pieces (6 patch rows x 4 pieces of 8 pixels x 128 B) + 28 dY pieces (4 pixels x 256 B)
+  auto issue = [&](int blk, int buf) {
+    const int b = blk / (C128_W / C128_RB), oh0 = (blk - b * (C128_W / C128_RB)) * C128_RB;
+    const unsigned base = lds0 + (unsigned)(buf * C128_BUF);
+    for (int id = wave; id < 24 + 28; id += 8) {
+      if (id < 24) {
+        const int prow = id >> 2, j = id & 3, ih = oh0 - 1 + prow;
+        const int dpx = lane >> 3, dpos = lane & 7, px = 8 * j + dpx;
+        const bool ok = (unsigned)ih < (unsigned)C128_W && px < C128_W;
+        dma16_c64(rsX, base + (unsigned)((prow * C128_PW + 1 + 8 * j) * 128), ok ? dpx * 256 + ((dpos ^ swz16(1 + px)) << 4) : OOBV,
+                  (unsigned)ih < (unsigned)C128_W ? ((b * C128_W + ih) * C128_W + 8 * j) * 256 + half * 128 : 0);
+      } else {
+        const int j = id - 24, pxi = lane >> 4, c16 = lane & 15, px = 4 * j + pxi;
+        dma16_c64(rsY, base + (unsigned)(C128_PATCH + j * 1024), pxi * 256 + ((c16 ^ (gsw8(px) << 1)) << 4),
+                  ((b * C128_W + oh0) * C128_W + 4 * j) * 256);
+      }
+    }
+  };
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xchunk = cw * 2 + (pp >> 1), sub = (pp & 1) * 4;
+
+  // ---- absolute LDS byte addresses of every transposed read (they follow the buffer toggle)
+  unsigned xo[C128_NKS][2][3], yo[2][4];
+#pragma unroll
+  for (int ks = 0; ks < C128_NKS; ++ks)
+#pragma unroll
+    for (int ab = 0; ab < 2; ++ab) {
+      int px = ks * 32 + 8 * g + q + 4 * ab;
+      px = px < C128_NPX ? px : C128_NPX - 1;                   // padded tail: its dY rows are zero, any valid address will do
+      const int rr = px / C128_W, cc = px - rr * C128_W;
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_)
+        xo[ks][ab][s_] = lds0 + (unsigned)(((rr * C128_PW + cc + s_) * 128) + ((xchunk ^ swz16(cc + s_)) << 4) + sub * 2);
+    }
+#pragma unroll
+  for (int ab = 0; ab < 2; ++ab) {
+    const int px = 8 * g + q + 4 * ab;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      yo[ab][i] = lds0 + (unsigned)(C128_PATCH + px * 256 + (((8 * nh + 2 * i + (pp >> 1)) ^ (gsw8(px) << 1)) << 4) + sub * 2);
+  }
+
+  int blk = wg, buf = 0;
+  if (blk < nblocks) issue(blk, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (; blk < nblocks; blk += nwg, buf ^= 1) {
+    const int nxt = blk + nwg;
+    if (nxt < nblocks) issue(nxt, buf ^ 1);                     // the other buffer: every wave finished reading it at the last barrier
+    // 36 steps = 4 k-steps x 9 taps.  G_n (issued at the top of step n) = one of the eight dY reads of the NEXT k-step (taps 0-7), then the
+    // x fragment of step n+2 (2 reads); LDS returns in order, so step n needs at most |G_(n-1)| + |G_n| reads outstanding.
+    constexpr int NST = C128_NKS * 9, ROWB = C128_PW * 128;
+    i32x2_c64 xl[3], xh[3], al[2][4], ah[2][4];
+#define TRRD(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { TRRD(al[0][i], yo[0][i], 0); TRRD(ah[0][i], yo[1][i], 0); }
+    static_for([&xl, &xh, &xo](auto N_) {
+      constexpr int n = decltype(N_)::value, r = n / 3, s_ = n - r * 3;
+      TRRD(xl[n], xo[0][0][s_], r * ROWB); TRRD(xh[n], xo[0][1][s_], r * ROWB);
+    }, std::make_integer_sequence<int, 2>{});
+    static_for([&xl, &xh, &al, &ah, &xo, &yo, &acc](auto N_) {
+      constexpr int n = decltype(N_)::value, ks = n / 9, t = n - ks * 9;
+      if constexpr (t < 8) {                                    // dY read t of the next k-step: n tile t >> 1, pixel row a / b = t & 1
+        constexpr int nk = ks + 1 < C128_NKS ? ks + 1 : ks, nb = (ks + 1) & 1;       // (last k-step: dummy re-read)
+        if constexpr ((t & 1) == 0) TRRD(al[nb][t >> 1], yo[0][t >> 1], nk * 8192); else TRRD(ah[nb][t >> 1], yo[1][t >> 1], nk * 8192);
+      }
+      {
+        constexpr int m = n + 2 < NST ? n + 2 : n, mk = m / 9, mt = m - mk * 9, r = mt / 3, s_ = mt - r * 3;
+        TRRD(xl[(n + 2) % 3], xo[mk][0][s_], r * ROWB); TRRD(xh[(n + 2) % 3], xo[mk][1][s_], r * ROWB);          // (last two steps: dummy re-read)
+      }
+      constexpr int size_n = t < 8 ? 3 : 2, size_p = n == 0 ? 2 : ((t + 8) % 9 < 8 ? 3 : 2);
+      if constexpr (t == 0)
+        asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(xl[n % 3]), "+v"(xh[n % 3]), "+v"(al[ks & 1][0]), "+v"(al[ks & 1][1]), "+v"(al[ks & 1][2]),
+                     "+v"(al[ks & 1][3]), "+v"(ah[ks & 1][0]), "+v"(ah[ks & 1][1]), "+v"(ah[ks & 1][2]), "+v"(ah[ks & 1][3]) : "n"(size_n + size_p));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xl[n % 3]), "+v"(xh[n % 3]) : "n"(size_n + size_p));
+      const i32x4v_c64 xv = {xl[n % 3][0], xl[n % 3][1], xh[n % 3][0], xh[n % 3][1]};
+      const bf16x8 bfv = __builtin_bit_cast(bf16x8, xv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const i32x4v_c64 av = {al[ks & 1][i][0], al[ks & 1][i][1], ah[ks & 1][i][0], ah[ks & 1][i][1]};
+        acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), bfv, acc[t][i], 0, 0, 0);
+      }
+    }, std::make_integer_sequence<int, NST>{});
+#undef TRRD
+    const unsigned d = buf ? (unsigned)(-C128_BUF) : (unsigned)C128_BUF;
+#pragma unroll
+    for (int ks = 0; ks < C128_NKS; ++ks)
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) xo[ks][ab][s_] += d;
+#pragma unroll
+    for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yo[ab][i] += d;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next block's pieces landed (and the dummy reads retired)
+    __builtin_amdgcn_s_barrier();
+  }
+  // flush: this workgroup's [128 n][9 taps][64 c of its half] block -> slab blockIdx.x
+  float* slab = p.ws + (size_t)blockIdx.x * 128 * 576;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) slab[(size_t)(nh * 64 + i * 16 + g * 4 + rr) * 576 + t * 64 + cw * 16 + li] = acc[t][i][rr];
+}
+
+// dw[n][tap*128 + half*64 + c] += sum over the slabs of that half (slab index half + 2w, w ascending) of slab[n][tap*64 + c]:
+// 64 float4 columns x 16 slab groups per block, fixed fold order (bit-reproducible)
+__global__ __launch_bounds__(1024) void wgrad_c128p_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nwg) {
+  const int half = blockIdx.y, i4 = blockIdx.x * 64 + threadIdx.x, gq = threadIdx.y;      // i4: float4 index inside [128][576]
+  const int per = (nwg + 15) / 16, w0 = gq * per, w1 = min(nwg, w0 + per);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int w = w0; w < w1; ++w) a += reinterpret_cast<const f32x4*>(ws + (size_t)(half + 2 * w) * 128 * 576)[i4];
+  __shared__ f32x4 sh[16][64];
+  sh[gq][threadIdx.x] = a;
+  __syncthreads();
+  if (gq == 0) {
+    const int e = i4 * 4, n = e / 576, k = e - n * 576, tap = k >> 6, c = k & 63;
+    f32x4* dst = reinterpret_cast<f32x4*>(dw + (size_t)n * 1152 + tap * 128 + half * 64 + c);
+    f32x4 t = *dst;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) t += sh[s_][threadIdx.x];
+    *dst = t;
+  }
+}
+
 extern "C" int vqa_slab_reduce(const float* ws, float* dw, int nslabs, long long n, hipStream_t st);
 
 extern "C" {
@@ -745,6 +918,29 @@ int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int 
 }
 // dw [64][576] fp32 (+=).  ws: scratch of >= vqa_conv3x3_c64_blocks(B,H,W) * 64*576 floats for the deterministic two-pass
 // accumulation (NULL or too small: fp32 atomics)
+// Stage-2 shape only (3x3 / 1 / pad 1, 128 -> 128 channels, 28 x 28 maps, bf16): slabs needed (= workgroups) or 0 when unsupported
+int vqa_wgrad3x3_c128_blocks(int B, int H, int W) {
+  static const int en = getenv("VQA_C128WP") ? atoi(getenv("VQA_C128WP")) : 1;
+  if (!en || H != C128_W || W != C128_W || B <= 0 || (size_t)B * H * W * 128 * 2 >= 0x7fffffffull) return 0;
+  const int nblocks = B * (C128_W / C128_RB);
+  int per_half = nblocks < 128 ? nblocks : 128;
+  return 2 * per_half;
+}
+// dw [128][9*128] fp32 (+=).  ws: vqa_wgrad3x3_c128_blocks(B, H, W) * 128*576 floats.
+int vqa_wgrad3x3_c128(const void* x, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t st) {
+  const int grid = vqa_wgrad3x3_c128_blocks(B, H, W);
+  if (!x || !dy || !dw || !ws || grid <= 0 || ws_floats < (long long)grid * 128 * 576) return VQA_EARG;
+  C128WgradParams p;
+  p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.ws = ws; p.B = B; p.bytes = (unsigned)((size_t)B * H * W * 128 * 2);
+  const size_t shm = (size_t)2 * C128_BUF;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_c128p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = true; }
+  hipLaunchKernelGGL(wgrad3x3_c128p_kernel, dim3(grid), dim3(512), shm, st, p);
+  hipLaunchKernelGGL(wgrad_c128p_reduce_kernel, dim3(128 * 576 / 4 / 64, 2), dim3(64, 16), 0, st, ws, dw, grid / 2);
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
+}
+
 int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t st) {
   const int grid = vqa_conv3x3_c64_blocks(B, H, W);
   if (!x || !dy || !dw || grid <= 0) return VQA_EARG;

@@ -189,6 +189,10 @@ class HipEngine:
             return False          # since the LDS-DMA rewrite the generic implicit GEMM is as fast for forward / data gradient
         return (self.dtype == torch.bfloat16 and Cin == 64 and Cout == 64 and R == 3 and stride == 1 and K.c64_blocks(B, H, W) > 0)
 
+    def _c128w_ok(self, B, H, W, Cin, Cout, stride):
+        """128 -> 128 channel 3x3/1 conv on 28 x 28 maps (stage 2): the 8-wave LDS-DMA weight-gradient kernel."""
+        return (self.dtype == torch.bfloat16 and Cin == 128 and Cout == 128 and stride == 1 and K.c128_wgrad_blocks(B, H, W) > 0)
+
     def _c64p_ok(self, B, H, W, Cin, Cout, R, stride):
         """64 -> 64 channel 3x3/1 conv without epilogue inputs: the 8-wave LDS-DMA patch kernel (156 vs 215 us forward, 152 vs 188 us
         data gradient at B=512)."""
@@ -861,6 +865,8 @@ class HipEngine:
         c64_2 = self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1)
         if self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1, wgrad=True):
             self._off_path([dy2], lambda: K.wgrad3x3_c64(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo), defer=last)
+        elif self._c128w_ok(B, Ho, Wo, Cout, Cout, 1):
+            self._off_path([dy2], lambda: K.wgrad3x3_c128(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo))
         else:
             self._off_path([dy2], lambda: K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T))
         slab1, nb1 = None, 0
@@ -882,6 +888,8 @@ class HipEngine:
         c64_1 = self._c64_ok(B, H, W, Cin, Cout, 3, stride)
         if self._c64_ok(B, H, W, Cin, Cout, 3, stride, wgrad=True):
             self._off_path([dy1], lambda: K.wgrad3x3_c64(rec["x"], dy1, LY.mat_of(G, self.E[p + ".conv1.weight"]), B, H, W), defer=last)
+        elif self._c128w_ok(B, H, W, Cin, Cout, stride):
+            self._off_path([dy1], lambda: K.wgrad3x3_c128(rec["x"], dy1, LY.mat_of(G, self.E[p + ".conv1.weight"]), B, H, W))
         else:
             self._off_path([dy1], lambda: K.wgrad(dy1, rec["x"], LY.mat_of(G, self.E[p + ".conv1.weight"]), M, Cout, 9 * Cin, g1, dtype=T))
         Md = B * H * W

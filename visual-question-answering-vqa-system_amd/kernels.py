@@ -121,6 +121,23 @@ def wgrad3x3_c64(x, dy, dw, B, H, W):
         PROFILE.append(("wgrad3x3_c64", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))   # prefix of both kernels (4-wave / 8-wave DMA)
 
 
+def c128_wgrad_blocks(B, H, W):
+    return L.count("vqa_wgrad3x3_c128_blocks", B, H, W)
+
+
+def wgrad3x3_c128(x, dy, dw, B, H, W):
+    """Stage-2 shape (128 -> 128 channels, 28 x 28): 8-wave LDS-DMA weight-gradient kernel, per-workgroup slabs + fixed-order reduce."""
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    wsf = c128_wgrad_blocks(B, H, W) * 128 * 576
+    ws = torch.empty(wsf, device=x.device, dtype=torch.float32)
+    call("vqa_wgrad3x3_c128", ptr(x), ptr(dy), ptr(dw), B, H, W, ptr(ws), wsf)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("wgrad3x3_c128p_kernel", 2.0 * B * H * W * 128 * 1152, e0, e1, 2 * B * H * W * 128 * 2))
+
+
 def dgrad_s2(dy, dyd, wt, B, H, W, C, Ho, Wo, N, R, pad, *, dtype):
     """Data gradient of a stride-2 conv (+ optional 1x1/2 shortcut) with rows grouped by parity class."""
     out = torch.empty((B * Ho * Wo, N), device=dy.device, dtype=dtype)
