@@ -73,6 +73,16 @@ if not args.only or "c64" in args.only:
     t = timeit(lambda: K.wgrad3x3_c64(x, dy, dw, B, H, H), args.iters)
     print(f"c64 patch wgrad        {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
 
+if (not args.only or "c128" in args.only) and K.c128_wgrad_blocks(B, 28, 28) > 0:
+    x = torch.randn(B * 28 * 28, 128, device=dev).to(T)
+    dy = torch.randn(B * 28 * 28, 128, device=dev).to(T)
+    dw = torch.zeros(128, 1152, device=dev)
+    fl = 2.0 * B * 28 * 28 * 128 * 1152
+    t = timeit(lambda: K.wgrad3x3_c128(x, dy, dw, B, 28, 28), args.iters)
+    print(f"c128 resident wgrad    {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   (kernel + fixed-order reduce)")
+    t = timeit(lambda: K.wgrad(dy, x, dw, B * 784, 128, 1152, (B, 28, 28, 128, 28, 28, 3, 3, 1, 1), dtype=T), args.iters)
+    print(f"c128 split-K wgrad     {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   (generic kernel + reduce)")
+
 if not args.only or "stem" in args.only:
     H = 224
     img = torch.randn(B, 3, H, H, device=dev)
