@@ -149,8 +149,7 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                                                          int B, int H, int W, int Ho, int Wo, const bf16_t* __restrict__ dpool,
                                                          const uint8_t* __restrict__ idx, const float* __restrict__ coef,
-                                                         const float* __restrict__ bc, int Hp, int Wp, int nsplit, float* __restrict__ ws,
-                                                         int dbg /* VQA_STEMW_DBG, measurement only: 1 no pool routing, 2 no im2col slice, 4 no MFMA, 8 no dY staging */) {
+                                                         const float* __restrict__ bc, int Hp, int Wp, int nsplit, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PW = 2 * Wo + 8;
   const int Wh = Wo / nsplit;                                        // pixels per unit: a row is contracted in nsplit pieces so that
@@ -174,6 +173,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       f_a[j] = bc[c0f + j]; f_b[j] = bc[64 + c0f + j]; f_c[j] = bc[128 + c0f + j];
     }
   }
+  // 32-bit buffer addressing for the gathers of the fused path and the patch fill (the 64-bit pointer arithmetic of the plain loads was
+  // 185 v_lshl_add_u64 in this kernel, which is VALU-bound in its staging phase)
+  const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(FUSED ? dpool : dy), 0, FUSED ? B * Hp * Wp * 64 * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(FUSED ? idx : reinterpret_cast<const uint8_t*>(dy)), 0, FUSED ? B * Hp * Wp * 64 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsImg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, B * 3 * H * W * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsDy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dy), 0, B * Ho * Wo * 64 * 2, 0x00020000);
   f32x4 acc[4][3];                                                   // wave owns k2 tiles 3*wave .. 3*wave+2, all 4 n tiles
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         const int c = row / PRW, pr = row - c * PRW, ih = ih_base + pr;
         const bool ok = cok && ih >= 0 && ih < H;
         const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
-        const float t = img[((size_t)(b * 3 + c) * H + ihc) * W + iwc];
+        const float t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsImg, (((b * 3 + c) * H + ihc) * W + iwc) * 4, 0, 0));
         vals[row] = ok ? t : 0.f;
       }
 #pragma unroll
@@ -204,15 +209,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       const int orow = unit / nsplit, px0 = (unit - orow * nsplit) * Wh;
       __syncthreads();                                               // patch ready / previous unit's MFMA reads done
       // dy row piece -> LDS (16-byte vectors), im2col slice -> LDS
-      const bf16_t* dyr = dy + (((size_t)b * Ho + oh0 + orow) * Wo + px0) * 64;
-      for (int v = tid; v < ((dbg & 8) ? 0 : Wh * 8); v += 256) {
+      const int dyr_b = (((b * Ho + oh0 + orow) * Wo + px0) * 64) * 2;     // byte offset of the row piece (32-bit buffer addressing)
+      for (int v = tid; v < Wh * 8; v += 256) {
         const int px = v >> 3, cv = v & 7;
-        u32x4 val = *reinterpret_cast<const u32x4*>(dyr + (size_t)px * 64 + cv * 8);      // dy row, or y row when FUSED
+        u32x4 val = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsDy, dyr_b + v * 16, 0, 0));      // dy row, or y row when FUSED
         if (FUSED) {
           Vec16<bf16_t> yy; yy.raw = val;
           float g8[8];
-          if (!(dbg & 1)) stem_route<bf16_t>(dpool, idx, yy, f_sc, f_sh, b, oh0 + orow, px0 + px, cv * 8, 64, Hp, Wp, g8);
-          else { for (int j = 0; j < 8; ++j) g8[j] = 0.f; }
+          stem_route_buf(rsP, rsI, yy, f_sc, f_sh, b, oh0 + orow, px0 + px, cv * 8, Hp, Wp, g8);
           Vec16<bf16_t> o;
 #pragma unroll
           for (int j = 0; j < 8; ++j) o.set(j, f_a[j] * g8[j] + f_b[j] * yy.get(j) + f_c[j]);
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[px * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned
         d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
       }
-      if (tid < 240 && !(dbg & 2)) {                                 // 10 pixels x 24 (c,r) pairs per pass
+      if (tid < 240) {                                               // 10 pixels x 24 (c,r) pairs per pass
         const int pair = tid % 24, c = pair / 7, r = pair - c * 7;
         const bf16_t* prow = patch + (c * PRW + 2 * orow + r) * PW + 2 * px0;
         for (int px = tid / 24; px < Wh; px += 10) {
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       }
       __syncthreads();
       typedef __attribute__((ext_vector_type(8))) short i16x8;
-      for (int ks = 0; ks < ((dbg & 4) ? 0 : MP / 32); ++ks) {
+      for (int ks = 0; ks < MP / 32; ++ks) {
         const bf16_t* yb = Dy + (ks * 32 + 8 * g + q) * LDD + 4 * pp;
         const bf16_t* xb = Acol + (ks * 32 + 8 * g + q) * LDA + wave * 48 + 4 * pp;
         bf16x8 af[4], bfv[3];
@@ -337,6 +341,7 @@ int vqa_stem_wgrad_blocks(int B, int H, int W) {
 int vqa_stem_wgrad(const float* img, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t st) {
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   if (!img || !dy || !dw || Ho % RBW || Wo % 16 || Wo > 256) return VQA_EARG;
+  if ((size_t)B * Ho * Wo * 64 * 2 >= 0x7fffffffull || (size_t)B * 3 * H * W * 4 >= 0x7fffffffull) return VQA_EARG;     // 32-bit buffer offsets
   const int nsplit = stem_nsplit(Wo);
   const int PW = 2 * Wo + 8, MP = (Wo / nsplit + 31) / 32 * 32;
   const size_t shm = (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
@@ -348,7 +353,7 @@ int vqa_stem_wgrad(const float* img, const void* dy, float* dw, int B, int H, in
   int grid = nblocks < cap ? nblocks : cap;
   float* w = (ws && ws_floats >= (long long)grid * 64 * 147) ? ws : nullptr;
   hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)dy, dw, B, H, W, Ho, Wo,
-                     (const bf16_t*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, nsplit, w, 0);
+                     (const bf16_t*)nullptr, (const uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, nsplit, w);
   VQA_LAUNCH_CHECK();
   return w ? vqa_slab_reduce(w, dw, grid, 64 * 147, st) : VQA_OK;
 }
@@ -358,6 +363,7 @@ int vqa_stem_wgrad_fused(const float* img, const void* y, const void* dpool, con
                          float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t st) {
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1, Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
   if (!img || !y || !dpool || !idx || !coef || !bcoef || !dw || Ho % RBW || Wo % 16 || Wo > 256) return VQA_EARG;
+  if ((size_t)B * Ho * Wo * 64 * 2 >= 0x7fffffffull || (size_t)B * 3 * H * W * 4 >= 0x7fffffffull) return VQA_EARG;     // 32-bit buffer offsets
   const int nsplit = stem_nsplit(Wo);
   const int PW = 2 * Wo + 8, MP = (Wo / nsplit + 31) / 32 * 32;
   const size_t shm = (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
@@ -369,7 +375,7 @@ int vqa_stem_wgrad_fused(const float* img, const void* y, const void* dpool, con
   int grid = nblocks < cap ? nblocks : cap;
   float* w = (ws && ws_floats >= (long long)grid * 64 * 147) ? ws : nullptr;
   hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(grid), dim3(256), shm, st, img, (const bf16_t*)y, dw, B, H, W, Ho, Wo,
-                     (const bf16_t*)dpool, idx, coef, bcoef, Hp, Wp, nsplit, w, getenv("VQA_STEMW_DBG") ? atoi(getenv("VQA_STEMW_DBG")) : 0);
+                     (const bf16_t*)dpool, idx, coef, bcoef, Hp, Wp, nsplit, w);
   VQA_LAUNCH_CHECK();
   return w ? vqa_slab_reduce(w, dw, grid, 64 * 147, st) : VQA_OK;
 }

@@ -37,3 +37,36 @@ __device__ __forceinline__ void stem_route(const T* __restrict__ dpool, const ui
     if (!(yy.get(j) * sc[j] + sh[j] > 0.f)) g[j] = 0.f;
 }
 
+// stem_route with 32-bit buffer offsets (raw buffer loads: no 64-bit address arithmetic per window, the range check replaces nothing --
+// the offsets are always clamped in range).  rsP / rsI: buffer resources of dpool (bf16) and idx (bytes).  Same sums, same order.
+__device__ __forceinline__ void stem_route_buf(__amdgpu_buffer_rsrc_t rsP, __amdgpu_buffer_rsrc_t rsI, const Vec16<bf16_t>& yy,
+                                               const float* sc, const float* sh, int b, int h, int w, int c0, int Ho, int Wo, float* g) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g[j] = 0.f;
+  const int oh_a = (h - 1) >> 1, oh_b = (h + 1) >> 1, ow_a = (w - 1) >> 1, ow_b = (w + 1) >> 1;
+  Vec16<bf16_t> d[4]; uint32_t ilo[4], ihi[4]; int code[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int oh = (k >> 1) ? oh_b : oh_a, ow = (k & 1) ? ow_b : ow_a;
+    const int r = h - (oh * 2 - 1), s = w - (ow * 2 - 1);
+    const bool ok = oh >= 0 && oh < Ho && ow >= 0 && ow < Wo && r >= 0 && r <= 2 && s >= 0 && s <= 2 &&
+                    !((k >> 1) && oh_b == oh_a) && !((k & 1) && ow_b == ow_a);          // do not count a window twice
+    code[k] = ok ? r * 3 + s : 255;                           // 255 never matches an argmax code (0..8)
+    const int ohc = min(max(oh, 0), Ho - 1), owc = min(max(ow, 0), Wo - 1);
+    const int o = ((b * Ho + ohc) * Wo + owc) * 64 + c0;
+    d[k].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, o * 2, 0, 0));
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+    const u32x2_t iw = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rsI, o, 0, 0));
+    ilo[k] = iw[0]; ihi[k] = iw[1];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int id = (int)(((j < 4 ? ilo[k] : ihi[k]) >> (8 * (j & 3))) & 0xff);
+      if (id == code[k]) g[j] += d[k].get(j);
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (!(yy.get(j) * sc[j] + sh[j] > 0.f)) g[j] = 0.f;
+}
