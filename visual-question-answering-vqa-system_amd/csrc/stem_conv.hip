@@ -210,20 +210,31 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       __syncthreads();                                               // patch ready / previous unit's MFMA reads done
       // dy row piece -> LDS (16-byte vectors), im2col slice -> LDS
       const int dyr_b = (((b * Ho + oh0 + orow) * Wo + px0) * 64) * 2;     // byte offset of the row piece (32-bit buffer addressing)
-      for (int v = tid; v < Wh * 8; v += 256) {
-        const int px = v >> 3, cv = v & 7;
-        u32x4 val = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsDy, dyr_b + v * 16, 0, 0));      // dy row, or y row when FUSED
-        if (FUSED) {
-          Vec16<bf16_t> yy; yy.raw = val;
-          float g8[8];
-          stem_route_buf(rsP, rsI, yy, f_sc, f_sh, b, oh0 + orow, px0 + px, cv * 8, Hp, Wp, g8);
-          Vec16<bf16_t> o;
+      if constexpr (FUSED) {
+        // item = (pixel pair (2q, 2q+1) of the piece, channel vector): the pair shares its pooling windows (stem_route_pair_buf)
+        for (int v = tid; v < (Wh >> 1) * 8; v += 256) {
+          const int pq = v >> 3, cv = v & 7;
+          Vec16<bf16_t> yy[2];
+          yy[0].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsDy, dyr_b + (2 * pq) * 128 + cv * 16, 0, 0));
+          yy[1].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsDy, dyr_b + (2 * pq + 1) * 128 + cv * 16, 0, 0));
+          float g8[2][8];
+          stem_route_pair_buf(rsP, rsI, yy, f_sc, f_sh, b, oh0 + orow, (px0 >> 1) + pq, cv * 8, Hp, Wp, g8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o.set(j, f_a[j] * g8[j] + f_b[j] * yy.get(j) + f_c[j]);
-          val = o.raw;
+          for (int q2 = 0; q2 < 2; ++q2) {
+            Vec16<bf16_t> o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.set(j, f_a[j] * g8[q2][j] + f_b[j] * yy[q2].get(j) + f_c[j]);
+            uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[(2 * pq + q2) * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned
+            d[0] = o.raw[0]; d[1] = o.raw[1]; d[2] = o.raw[2]; d[3] = o.raw[3];
+          }
         }
-        uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[px * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned
-        d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
+      } else {
+        for (int v = tid; v < Wh * 8; v += 256) {
+          const int px = v >> 3, cv = v & 7;
+          const u32x4 val = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsDy, dyr_b + v * 16, 0, 0));
+          uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[px * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned
+          d[0] = val[0]; d[1] = val[1]; d[2] = val[2]; d[3] = val[3];
+        }
       }
       if (tid < 240) {                                               // 10 pixels x 24 (c,r) pairs per pass
         const int pair = tid % 24, c = pair / 7, r = pair - c * 7;

@@ -70,3 +70,48 @@ __device__ __forceinline__ void stem_route_buf(__amdgpu_buffer_rsrc_t rsP, __amd
   for (int j = 0; j < 8; ++j)
     if (!(yy.get(j) * sc[j] + sh[j] > 0.f)) g[j] = 0.f;
 }
+
+// The same routing for TWO horizontally adjacent pixels (h, 2j) and (h, 2j+1) at once: column 2j lies in pooling-window column j only
+// (s = 1), column 2j+1 in window columns j (s = 2) and j+1 (s = 0); window rows {(h-1)>>1, (h+1)>>1} (one row when h is even).  2 or 4
+// window loads and unpacks for 2 pixels instead of 4 per pixel -- the staging of the fused stem weight gradient is VALU-bound.  Sums
+// are formed in the same order as stem_route (window row a before b, column j before j+1), so the values are bit-identical.
+__device__ __forceinline__ void stem_route_pair_buf(__amdgpu_buffer_rsrc_t rsP, __amdgpu_buffer_rsrc_t rsI, const Vec16<bf16_t> (&yy)[2],
+                                                    const float* sc, const float* sh, int b, int h, int j, int c0, int Ho, int Wo,
+                                                    float (&g)[2][8]) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int jx = 0; jx < 8; ++jx) g[q][jx] = 0.f;
+  const int oh_a = (h - 1) >> 1, oh_b = (h + 1) >> 1;
+#pragma unroll
+  for (int kr = 0; kr < 2; ++kr) {
+    if (kr == 1 && oh_b == oh_a) break;                       // wave-uniform (h is the unit's row)
+    const int oh = kr ? oh_b : oh_a, r = h - (oh * 2 - 1);
+    const bool rok = oh >= 0 && oh < Ho;
+    const int ohc = min(max(oh, 0), Ho - 1);
+    Vec16<bf16_t> d[2]; u32x2_t iw[2]; bool ok[2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      const int ow = j + kc;
+      ok[kc] = rok && ow < Wo;
+      const int o = ((b * Ho + ohc) * Wo + min(ow, Wo - 1)) * 64 + c0;
+      d[kc].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, o * 2, 0, 0));
+      iw[kc] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rsI, o, 0, 0));
+    }
+    const int c_e = ok[0] ? r * 3 + 1 : 255, c_o0 = ok[0] ? r * 3 + 2 : 255, c_o1 = ok[1] ? r * 3 : 255;
+#pragma unroll
+    for (int jx = 0; jx < 8; ++jx) {
+      const int i0 = (int)((iw[0][jx >> 2] >> (8 * (jx & 3))) & 0xff), i1 = (int)((iw[1][jx >> 2] >> (8 * (jx & 3))) & 0xff);
+      const float d0 = d[0].get(jx), d1 = d[1].get(jx);
+      if (i0 == c_e) g[0][jx] += d0;
+      if (i0 == c_o0) g[1][jx] += d0;
+      if (i1 == c_o1) g[1][jx] += d1;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int jx = 0; jx < 8; ++jx)
+      if (!(yy[q].get(jx) * sc[jx] + sh[jx] > 0.f)) g[q][jx] = 0.f;
+}
