@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     *reinterpret_cast<u32x4*>(&Wl[n * LDW + kv * 8]) = *reinterpret_cast<const u32x4*>(&wst[n * KP + kv * 8]);
   }
   const int ih_base = 2 * oh0 - 3;
+  const __amdgpu_buffer_rsrc_t rsImg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, (int)gridDim.x / rblocks * 3 * H * W * 4, 0x00020000);   // 32-bit offsets
   for (int x = tid; x < PW; x += 256) {                    // lanes walk x (coalesced); all 3*PR row loads are issued
     const int iw = x - 3;                                    // back to back before the first use (latency overlapped)
     const bool cok = iw >= 0 && iw < W;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       const int c = row / PR, pr = row - c * PR, ih = ih_base + pr;
       const bool ok = cok && ih >= 0 && ih < H;
       const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);      // always-valid address: unconditional load
-      const float t = img[((size_t)(b * 3 + c) * H + ihc) * W + iwc];
+      const float t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsImg, (((b * 3 + c) * H + ihc) * W + iwc) * 4, 0, 0));
       vals[row] = ok ? t : 0.f;
     }
 #pragma unroll
@@ -331,7 +332,7 @@ int vqa_stem_pack(const float* w_krsc, void* wstem /* [64][192] bf16 */, hipStre
 // bf16 only.  img NCHW fp32 [B][3][H][W]; out NHWC bf16 [B][Ho][Wo][64]; stats [vqa_stem_conv_blocks][2][64] or NULL
 int vqa_stem_conv(const float* img, const void* wstem, void* out, float* stats, int B, int H, int W, hipStream_t st) {
   const int nb = vqa_stem_conv_blocks(B, H, W);
-  if (!img || !wstem || !out || nb <= 0) return VQA_EARG;
+  if (!img || !wstem || !out || nb <= 0 || (size_t)B * 3 * H * W * 4 >= 0x7fffffffull) return VQA_EARG;      // 32-bit buffer offsets into the image
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1, PW = 2 * Wo + 8;
   const size_t shm = (size_t)(3 * PR * PW + 64 * LDW) * 2 + 4 * 64 * 2 * 4;
   static size_t attr = 0;
