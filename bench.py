@@ -1,15 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: image-question pairs/sec of a full train step (forward + CrossEntropy + backward + gradient
-all-reduce + clip_grad_norm_(1.0) + AdamW) of the VQA model, B=512 per GPU, 224x224 images, 20 tokens, bf16 MFMA.
+all-reduce + clip_grad_norm_(1.0) + AdamW) of the VQA model.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W                      # BASELINE configs[2]: B=512/GPU, 224x224, 20 tokens, bf16 MFMA
+  python bench.py --config stress                                    # BASELINE configs[4]: B=256/GPU, 384x384 -> 144 image tokens,
+                                                                     #   d=512, 8 text layers, 2000 answers, bf16
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : dominant kernel (by time) of a train step, algorithmic FLOP/s from live event timings vs gfx950 MFMA peak
+  roofline     : dominant GEMM-class kernel (by time) of a train step, algorithmic FLOP/s from live event timings vs the gfx950 MFMA
+                 peak, plus `hbm_classes`: the HBM-bound kernel classes (BatchNorm passes, SE / spatial attention, stem pooling,
+                 token-side elementwise, optimizer tail) with algorithmic bytes / time vs 8 TB/s
   cpu_baseline : the CPU oracle (this repo's PyTorch restatement of the reference, parity-pinned by tests/golden) timed on
-                 the host cores on a bounded sample of the same workload (N=1 only).
+                 the host cores on a bounded sample of the same workload (N=1 only); cores and CPU model stated
+  extras       : forward-only pairs/s, and pairs/s through the restated loop of the UNCHANGED caller (training/train.py:168-212:
+                 torch AdamW over the 164 parameter views, clip_grad_norm_, loss.item(), accuracy.update) on the drop-in model.
 Inputs are synthetic (DemoVQADataset shapes, data/dataset.py:420-436) and resident in HBM before the timed region.
+
+--backend gloo lets N ranks share ONE GPU (tests/test_gpu_bench_ranks.py runs this whole file with 2 ranks on the 1-GPU test box);
+--force-reducer runs the bucketed all-reduce choreography (communication stream, events, async RCCL all-reduce per bucket) in a
+world of one rank.
 """
 import argparse
 import importlib
@@ -21,26 +31,46 @@ import time
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, REPO)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
 PKG = "visual-question-answering-vqa-system_amd"
-FLOP_PER_PAIR = 11.311e9          # forward 3.849 + backward 7.462 GFLOP per pair
 PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+HBM_PEAK = 8000.0                        # GB/s, MI355X_MICROARCH.md
+
+# BASELINE.json configs[2] (default; configs[1] with --dtype fp32 --batch 256) and configs[4] (stress)
+CONFIGS = {
+    "default": dict(model={}, image=224, seq=20, vocab_ids=1000, batch=512, ntok=49, baseline_idx=2,
+                    desc="3x224x224 images, 20 tokens, d=256, 4 text layers, 49 image tokens, 1000 answers"),
+    "stress": dict(model=dict(embed_dim=512, num_transformer_layers=8, num_answers=2000), image=384, seq=20, vocab_ids=1000, batch=256,
+                   ntok=144, baseline_idx=4,
+                   desc="3x384x384 images -> 144 image tokens, 20 tokens, d=512, 8 text layers, 2000 answers"),
+}
 
 
-def synth_batch(B, device, seed):
+def synth_batch(B, device, seed, image=224, seq=20, vocab=1000, answers=1000):
     g = torch.Generator(device=device).manual_seed(seed)
-    images = torch.randn(B, 3, 224, 224, device=device, generator=g)
-    ids = torch.randint(0, 1000, (B, 20), device=device, generator=g)
-    lens = torch.randint(5, 21, (B,), device=device, generator=g)
-    mask = (torch.arange(20, device=device)[None, :] < lens[:, None]).long()
-    answers = torch.randint(0, 1000, (B,), device=device, generator=g)
-    return images, ids, mask, answers
+    images = torch.randn(B, 3, image, image, device=device, generator=g)
+    ids = torch.randint(0, vocab, (B, seq), device=device, generator=g)
+    lens = torch.randint(5, seq + 1, (B,), device=device, generator=g)
+    mask = (torch.arange(seq, device=device)[None, :] < lens[:, None]).long()
+    ans = torch.randint(0, answers, (B,), device=device, generator=g)
+    return images, ids, mask, ans
 
 
-def cpu_baseline(seconds_budget=24.0):
-    """the reference's train-step recipe (fp32, model.train(), dropout on) on the host cores at B=4
-    (BASELINE configs[0]) and B=32 (the reference's default batch, utils/config.py:159), median step time of a bounded sample.
-    `value` is the B=32 figure; the B=4 one rides along."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(conf, seconds_budget=24.0):
+    """the reference's train-step recipe (fp32, model.train(), dropout on) on the host cores, median step
+    time of a bounded sample.  Default config: B=4 (BASELINE configs[0]) and B=32 (the reference's default batch,
+    utils/config.py:159), `value` is the B=32 figure; stress config: B=4 only (a 384x384 step costs ~3x)."""
     from oracle import vqa_oracle as O
     try:
         avail = len(os.sched_getaffinity(0))
@@ -48,11 +78,14 @@ def cpu_baseline(seconds_budget=24.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))      # a 1-GPU box is given a 16-CPU share; more threads than that only thrash
     torch.set_num_threads(cores)
-    cfg = O.full_config()
+    cfg = O.full_config(**conf["model"])
+    if conf["ntok"] != 49:
+        cfg["num_image_tokens"] = conf["ntok"]
+    plan = ((4, seconds_budget / 3, 2), (32, seconds_budget * 2 / 3, 1)) if conf["image"] == 224 else ((4, seconds_budget, 1),)
     res = {}
-    for B, budget, warm in ((4, seconds_budget / 3, 2), (32, seconds_budget * 2 / 3, 1)):
+    for B, budget, warm in plan:
         sd = O.init_state_dict(cfg, 0)
-        images, ids, mask, answers = O.synthetic_batch(B, seed=1)
+        images, ids, mask, answers = O.synthetic_batch(B, seed=1, image_size=conf["image"], seq_len=conf["seq"], num_answers=cfg["num_answers"])
         tr = O.OracleTrainer(sd, cfg)
         for _ in range(warm):
             tr.step(images, ids, mask, answers)
@@ -67,25 +100,64 @@ def cpu_baseline(seconds_budget=24.0):
         times.sort()
         med = times[len(times) // 2]
         res[B] = (B / med, len(times), t2 - t0)
-    v32, n32, el32 = res[32]
-    v4, n4, el4 = res[4]
-    return {"value": round(v32, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "value_b4": round(v4, 3), "value_b32": round(v32, 3),
-            "sample": f"median of {n32} fp32 train steps of the CPU oracle at batch 32 ({el32:.1f}s) and of {n4} at batch 4 ({el4:.1f}s); "
-                      "same model/config and step recipe (fwd+CE+bwd+clip+AdamW), dropout on"}
+    big = max(res)
+    v, n, el = res[big]
+    out = {"value": round(v, 3), "unit": "pairs/s", "cores": cores, "cpu_model": cpu_model_name(), "kind": "port",
+           "sample": "; ".join(f"median of {res[b][1]} fp32 train steps of the CPU oracle at batch {b} ({res[b][2]:.1f}s)" for b in sorted(res))
+                     + "; same model/config and step recipe (fwd+CE+bwd+clip+AdamW), dropout on"}
+    for b in res:
+        out[f"value_b{b}"] = round(res[b][0], 3)
+    return out
 
 
-def main():
+def dropin_loop(model, batch, steps, warmup):
+    """training/train.py:168-212 restated (non-AMP branch :198-208): what a user of the UNCHANGED Trainer gets from the drop-in --
+    torch.optim.AdamW over the 164 parameter views, autograd through the vqa_hip custom ops, clip_grad_norm_, and the two host
+    syncs per step (loss.item(), accuracy.update's argmax/.cpu())."""
+    images, ids, mask, answers = batch
+    crit = torch.nn.CrossEntropyLoss()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999))
+    correct = total = 0
+
+    def one():
+        nonlocal correct, total
+        opt.zero_grad()
+        logits, _ = model(images, ids, mask)
+        loss = crit(logits, answers)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        opt.step()
+        lv = loss.item()                                               # train.py:211
+        pred = logits.detach().argmax(dim=-1).cpu()                    # utils/metrics.py:73-94
+        correct += int((pred == answers.cpu()).sum().item()); total += pred.numel()
+        return lv
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    return images.shape[0] * steps / (time.perf_counter() - t0)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)        # SURVEY 8(d): >= 10 warm-up steps, >= 50 timed steps
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
+    ap.add_argument("--config", default="default", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 512, stress config 256)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: ranks may share one GPU (rehearsal on a 1-GPU box)")
+    ap.add_argument("--force-reducer", action="store_true", help="bucketed all-reduce choreography even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward-only and drop-in-loop secondary measurements")
     ap.add_argument("--no-overlap", action="store_true", help="no RCCL/backward overlap")
     ap.add_argument("--serial", action="store_true", help="single-stream execution (no text-encoder / weight-gradient side streams)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    conf = CONFIGS[args.config]
+    batch = args.batch or conf["batch"]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,22 +165,38 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
+    ndev = torch.cuda.device_count()
+    local_dev = local % max(1, ndev) if args.backend == "gloo" else local      # gloo rehearsal: ranks may share a GPU
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    import torch.distributed as dist
+    use_dist = world > 1 or args.force_reducer
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = importlib.import_module(PKG)
     M = pkg.load_dropin()
-    model = M.VQAModel(compute_dtype=args.dtype, seed=1234).to(dev).train()
-    trainer = pkg.trainer.HipTrainer(model, overlap=not args.no_overlap)
+    mkw = dict(conf["model"])
+    if conf["ntok"] != 49:
+        mkw["num_image_tokens"] = conf["ntok"]
+    model = M.VQAModel(compute_dtype=args.dtype, seed=1234, **mkw).to(dev).train()
+    trainer = pkg.trainer.HipTrainer(model, overlap=not args.no_overlap, force_reducer=args.force_reducer)
     if args.serial:
         trainer.engine.two_streams = False
-    images, ids, mask, answers = synth_batch(args.batch, dev, 1234 + rank)
+    data = synth_batch(batch, dev, 1234 + rank, conf["image"], conf["seq"], conf["vocab_ids"], model.num_answers)
+    images, ids, mask, answers = data
+    flop_pair = pkg.flops.train_flops(model.config, conf["image"], conf["image"], conf["seq"])
+    fwd_flop_pair = pkg.flops.forward_flops(model.config, conf["image"], conf["image"], conf["seq"])["total"]
+    es = 2 if args.dtype == "bf16" else 4
+    act_bytes_pair = 3.0 * es * pkg.flops.activation_elements(model.config, conf["image"], conf["image"], conf["seq"])
+    nparam = sum(e.numel for e in model._param_entries)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -116,14 +204,14 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    note(f"model ready, batch {args.batch}/GPU x {world} GPU(s), dtype {args.dtype}")
+    note(f"model ready ({args.config}), batch {batch}/GPU x {world} rank(s), dtype {args.dtype}, backend {args.backend if use_dist else 'none'}")
     for _ in range(args.warmup):
-        trainer.step(images, ids, mask, answers)
+        trainer.step(*data)
     barrier()
     note("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.step(images, ids, mask, answers)
+        trainer.step(*data)
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
@@ -131,9 +219,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     loss = float(trainer.loss.item())
+    trainer.check()                        # (one host sync, outside the timed region: raises if a step was rejected)
     ms = el / args.steps * 1e3
     note(f"timed region done: {ms:.2f} ms/step")
-    value = args.batch * world * args.steps / el
+    value = batch * world * args.steps / el
 
     # ---- live per-kernel timing of one more step (events on the launch stream) -> roofline of the dominant kernel
     roof = None
@@ -143,27 +232,37 @@ def main():
     # EVERY rank runs them (a step issues the bucket all-reduces: the collectives must stay matched); only rank 0 records events.
     was = trainer.engine.two_streams
     trainer.engine.two_streams = False
-    trainer.step(images, ids, mask, answers)
+    trainer.step(*data)
     if rank == 0:
         K.PROFILE = []
-    trainer.step(images, ids, mask, answers)
+    trainer.step(*data)
     torch.cuda.synchronize()
     trainer.engine.two_streams = was
     if rank == 0:
-        agg = {}
+        agg, hbm = {}, {}
         for name, flops, e0, e1, nbytes in K.PROFILE:
+            tsec = e0.elapsed_time(e1) * 1e-3
+            if name.startswith("hbm:"):
+                _, cls, entry = name.split(":", 2)
+                h = hbm.setdefault(cls, [0.0, 0.0, 0, {}])
+                h[0] += tsec; h[1] += nbytes; h[2] += 1
+                pe = h[3].setdefault(entry, [0.0, 0.0, 0]); pe[0] += tsec; pe[1] += nbytes; pe[2] += 1
+                continue
             a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
-            a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += flops; a[2] += 1; a[3] += nbytes
+            a[0] += tsec; a[1] += flops; a[2] += 1; a[3] += nbytes
         K.PROFILE = None
         gemm_time = sum(a[0] for a in agg.values())
         name, (tt, fl, n, nb) = max(agg.items(), key=lambda kv: kv[1][0])
         ach = fl / tt / 1e12
         traffic = None                      # HBM bytes per launch from rocprofv3 PMC passes (tools/hbm_traffic.py), if recorded
         import glob
-        cands = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
+        tag = "" if args.config == "default" else args.config + "_"
+        cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{tag}hbm_traffic.json")))
+        if args.config == "default":
+            cands = [c for c in cands if "stress" not in os.path.basename(c)]
         tpath = cands[-1] if cands else ""
         tsrc = None
-        if tpath and args.batch == 512 and args.dtype == "bf16":
+        if tpath and batch == conf["batch"] and args.dtype == "bf16":
             tb = tn = 0.0                           # the PROFILE name is a prefix of the full template instantiation(s):
             for kname, v in json.load(open(tpath))["kernels"].items():      # launch-weighted mean over all of them
                 if name.rstrip('>') in kname:
@@ -172,31 +271,72 @@ def main():
                 traffic = round(tb / tn)
                 tsrc = ("profiles/" + os.path.basename(tpath) + " (static: separate rocprofv3 --pmc passes of this command, "
                         "tools/hbm_traffic.py; NOT measured in this run)")
+        hbm_time = sum(h[0] for h in hbm.values())
+        hbm_classes = {cls: {"ms": round(h[0] * 1e3, 3), "GB": round(h[1] / 1e9, 3), "GBps": round(h[1] / h[0] / 1e9, 1),
+                             "frac_of_hbm_peak": round(h[1] / h[0] / 1e9 / HBM_PEAK, 4), "launches": h[2],
+                             "entries": {k: {"ms": round(v[0] * 1e3, 3), "GBps": round(v[1] / v[0] / 1e9, 1), "n": v[2]}
+                                         for k, v in sorted(h[3].items(), key=lambda kv: -kv[1][0])}}
+                       for cls, h in sorted(hbm.items(), key=lambda kv: -kv[1][0])}
+        step_bytes = batch * act_bytes_pair + nparam * 4 * 7 + nparam * 4
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                 "frac": round(ach / PEAK[args.dtype], 4), "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(nb / n), "launches_per_step": n,
                 "avg_launch_us": round(tt / n * 1e6, 2), "flop_per_launch": fl / n,
                 "measured": "live HIP events on the launch stream, one single-stream step after the timed region",
                 "kernel_time_ms_per_step": round(tt * 1e3, 3), "all_gemm_time_ms_per_step": round(gemm_time * 1e3, 3),
-                "step_tflops": round(value / world * FLOP_PER_PAIR / 1e12, 2),
-                "per_kernel": {k: {"ms": round(v[0] * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1), "n": v[2]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
-    if world > 1:
+                "flop_per_pair": flop_pair, "step_tflops": round(value / world * flop_pair / 1e12, 2),
+                "step_frac_of_mfma_peak": round(value / world * flop_pair / 1e12 / PEAK[args.dtype], 4),
+                "per_kernel": {k: {"ms": round(v[0] * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1), "n": v[2]} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])},
+                "hbm_bound_time_ms_per_step": round(hbm_time * 1e3, 3), "hbm_peak_GBps": HBM_PEAK, "hbm_classes": hbm_classes,
+                "step_algorithmic_bytes": round(step_bytes),
+                "step_algorithmic_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
+                "step_frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK, 4)}
+    if use_dist:
         dist.barrier()
+
+    # ---- secondary figures (1 rank only: neither issues collectives)
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        eng = trainer.engine
+        maskf = mask.float()
+        n_f = max(5, min(20, args.steps))
+        for _ in range(3):
+            eng.forward(images, ids, maskf, True, False, need_tape=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_f):
+            eng.forward(images, ids, maskf, True, False, need_tape=True)
+        torch.cuda.synchronize()
+        fwd = batch * n_f / (time.perf_counter() - t0)
+        n_d = max(5, min(10, args.steps))
+        torch.cuda.empty_cache()
+        note("timing the restated train.py loop on the drop-in model")
+        dl = dropin_loop(model, data, n_d, 3)
+        extras = {"forward_only_pairs_s": round(fwd, 1), "forward_only_tflops": round(fwd * fwd_flop_pair / 1e12, 1),
+                  "forward_only_note": f"training-mode forward (batch statistics, dropout, tape kept), {n_f} steps",
+                  "dropin_loop_pairs_s": round(dl, 1),
+                  "dropin_loop_note": f"training/train.py:168-212 restated (non-AMP branch): model(...) through the vqa_hip custom ops + autograd, "
+                                      f"torch.optim.AdamW over 164 views, clip_grad_norm_, loss.item(), argmax.cpu(); {n_d} steps"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         note("timing the CPU oracle baseline (bounded sample)")
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(conf)
+    out = None
     if rank == 0:
+        bidx = conf["baseline_idx"] if args.dtype == "bf16" else 1
         out = {"metric": "image-question pairs/sec (train step)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"VQA train step fwd+CE+bwd+allreduce+clip+AdamW, batch {args.batch}/GPU, 3x224x224 images, 20 tokens, "
-                                      f"d=256, 1000 answers, dropout on (BASELINE configs[{2 if args.dtype == 'bf16' else 1}])",
-                          "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-               "final_loss": round(loss, 4), "roofline": roof, "cpu_baseline": cpu}
+               "config": {"workload": f"VQA train step fwd+CE+bwd+allreduce+clip+AdamW, batch {batch}/GPU, {conf['desc']}, "
+                                      f"dropout on (BASELINE configs[{bidx}])",
+                          "name": args.config, "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
+                          "backend": (args.backend if use_dist else None), "reducer": ("forced" if args.force_reducer and world == 1 else ("on" if world > 1 else "off")),
+                          "bytes_allreduced_per_step": trainer.reducer.bytes_reduced // max(1, args.steps + args.warmup + 2) if trainer.reducer.active else 0},
+               "final_loss": round(loss, 4), "roofline": roof, "cpu_baseline": cpu, "extras": extras}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -202,11 +202,14 @@ int vqa_fold_group(int njobs, const float* const* part, const int* nrows, const 
 int vqa_cross_entropy(int dtype, const void* logits, const long long* targets, float* loss, void* dlogits, float* logits_f32,
                       int B, int N, float gscale, int* err, float* ws /* B floats, or NULL: float atomics on *loss */, hipStream_t stream);
 int vqa_convert(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
-/* clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (training/train.py:204-208,127-132) */
+/* clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (training/train.py:204-208,127-132).
+   skip (device int, may be NULL): when skip[0] != 0 the launch changes NOTHING (parameters, moments) and adds skip[0] to
+   skipped[0] and 1 to skipped[1] (device int[2], may be NULL) -- a step whose CrossEntropy saw an out-of-range target raises in
+   the reference before optimizer.step(), so the model must survive it. */
 int vqa_sumsq(const float* g, long long n, float* out /* >= 2049 floats: [0] result (bit-reproducible), rest scratch */, hipStream_t stream);
 int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, float bias_corr1, float bias_corr2, const float* sumsq, float max_norm, float gscale,
-              hipStream_t stream);
+              const int* skip, int* skipped, hipStream_t stream);
 
 /* ---- input pipeline on the GPU -----------------------------------------------------------------
  * vqa_image_normalize: torchvision ToTensor + Normalize of data/preprocess.py:34-35,117-121 -- uint8 HWC [B][H][W][3] ->

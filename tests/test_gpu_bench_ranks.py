@@ -1,0 +1,139 @@
+"""GPU: the N>1 code paths executed for real on the ONE GPU of the test box (north_star: "reported at 1, 2, 4 and 8 GPUs").
+
+* the WHOLE bench.py main() with 2 ranks -- fresh spawned processes sharing GPU 0, gloo transport: process-group init, warm-up,
+  timed loop with the bucketed gradient all-reduce, barriers, max-over-ranks time, the all-rank profiling steps, one JSON line on
+  rank 0, clean exit;
+* a world-size-1 RCCL ("nccl") group with the reducer forced on: HipTrainer.step issues every bucket as an async RCCL all-reduce on
+  the communication stream behind the segment events and waits for them before clip + AdamW -- the exact stream choreography of an
+  8-GPU job; its result must be bit-equal to the step without any reducer;
+* bench.py --force-reducer through the same RCCL group.
+Every rank is a fresh child process (mp spawn): a process that has touched the GPU is never re-exec'ed.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _bench_worker(rank, world, port, argv, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    out = bench.main(argv)
+    q.put((rank, out))
+
+
+def _run_ranks(target, world, args, timeout=600):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    for p in ps:
+        p.start()
+    try:
+        res = dict(q.get(timeout=timeout) for _ in range(world))
+        for p in ps:
+            p.join(timeout=120)
+            assert p.exitcode == 0, p.exitcode
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.kill()                      # exactly the processes started here
+    return res
+
+
+def test_whole_bench_main_with_two_ranks_on_one_gpu_over_gloo():
+    argv = ["--gpus", "2", "--backend", "gloo", "--batch", "8", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    res = _run_ranks(_bench_worker, 2, (argv,))
+    assert res[1] is None                                         # only rank 0 prints / returns the line
+    out = res[0]
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2" and out["config"]["reducer"] == "on"
+    assert out["value"] > 0 and abs(out["value"] - 16 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-3
+    assert out["final_loss"] == out["final_loss"] and 5.0 < out["final_loss"] < 9.0        # ln(1000) = 6.9 at random init
+    from _pkg import sub
+    from oracle import vqa_oracle as O
+    LY = sub("layout")
+    nflat = LY.flat_size(LY.build_entries(O.full_config()))
+    assert out["config"]["bytes_allreduced_per_step"] == 4 * nflat + 4     # every bucket of the flat gradient + the bad-target counter
+    roof = out["roofline"]
+    assert roof["frac"] > 0 and roof["hbm_classes"]["bn"]["GBps"] > 0      # the all-rank profiling steps ran (collectives matched)
+    assert out["cpu_baseline"] is None and out["extras"] is None           # N > 1: rank 0 skips the single-rank extras
+
+
+def _nccl1_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from _pkg import pkg
+    from oracle import vqa_oracle as O
+    P = pkg()
+    M = P.load_dropin()
+    results = {}
+    for tag, cfg, dtype, bkw in (
+            ("small_fp32", O.full_config(embed_dim=64, vocab_size=200, num_answers=40), "fp32", dict(image_size=64, seq_len=12, vocab=200, num_answers=40)),
+            ("full_bf16", O.full_config(), "bf16", {})):
+        sd = O.init_state_dict(cfg, 5, jitter=True)
+        batch = [t.cuda() for t in O.synthetic_batch(4, seed=300, **bkw)]
+
+        def run(force):
+            m = M.VQAModel(**cfg, compute_dtype=dtype)
+            m.load_state_dict(sd)
+            m = m.to("cuda").train()
+            tr = P.trainer.HipTrainer(m, lr=1e-3, force_reducer=force)
+            comm_streams = set()
+            if force:
+                orig = dist.all_reduce
+
+                def spy(t, *a, **k):
+                    assert k.get("async_op") is True and t.is_cuda
+                    comm_streams.add(torch.cuda.current_stream().cuda_stream)
+                    return orig(t, *a, **k)
+                dist.all_reduce = spy
+            main_stream = torch.cuda.current_stream().cuda_stream
+            losses = []
+            try:
+                for _ in range(3):
+                    loss, _ = tr.step(*batch)
+                    losses.append(loss.clone())
+                torch.cuda.synchronize()
+            finally:
+                if force:
+                    dist.all_reduce = orig
+            tr.check()
+            return m._flat.detach().clone(), tr.G.clone(), torch.cat(losses), tr, comm_streams, main_stream
+        p0, g0, l0, tr0, _, _ = run(False)
+        p1, g1, l1, tr1, comm, main_stream = run(True)
+        results[tag] = dict(params_equal=torch.equal(p0, p1), grads_equal=torch.equal(g0, g1), loss_equal=torch.equal(l0, l1),
+                            finite=bool(torch.isfinite(p1).all()), active0=tr0.reducer.active, active1=tr1.reducer.active,
+                            world=tr1.world, bytes1=tr1.reducer.bytes_reduced, nflat=p1.numel(),
+                            on_comm_stream=(len(comm) == 1 and main_stream not in comm), nbuckets=len(tr1.buckets))
+    q.put((0, results))
+    dist.destroy_process_group()
+
+
+def test_forced_reducer_over_a_one_rank_rccl_group_is_bit_equal_to_no_reducer():
+    res = _run_ranks(_nccl1_worker, 1, ())[0]
+    for tag, r in res.items():
+        assert r["active1"] and not r["active0"] and r["world"] == 1, (tag, r)
+        assert r["on_comm_stream"], (tag, r)                     # every RCCL all-reduce was issued on the reducer's own stream
+        assert r["bytes1"] == 3 * (4 * r["nflat"] + 4), (tag, r)  # three steps: all 8 buckets of the flat gradient + the counter
+        assert r["finite"] and r["params_equal"] and r["grads_equal"] and r["loss_equal"], (tag, r)
+
+
+def test_bench_force_reducer_through_rccl_world1():
+    argv = ["--gpus", "1", "--force-reducer", "--batch", "8", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+    out = _run_ranks(_bench_worker, 1, (argv,))[0]
+    assert out["n_gpus"] == 1 and out["config"]["reducer"] == "forced" and out["config"]["backend"] == "nccl"
+    assert out["config"]["bytes_allreduced_per_step"] > 4 * 19_000_000
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0

@@ -61,6 +61,28 @@ def test_config2_bf16_batch512_eval_matches_oracle_on_first_samples():
     assert (big[-4:].cpu() - ref2).abs().max().item() < 5e-2
 
 
+def test_config4_stress_bf16_batch256_eval_matches_oracle_on_first_and_last_samples():
+    """BASELINE configs[4] at the size bench.py --config stress times (B=256 per GPU, 384x384 -> 144 image tokens, d=512, 8 text
+    layers, 2000 answers, bf16): eval-mode logits of the first / last samples of the full batch against the CPU oracle run on just
+    those samples.  Oracle parity only -- the reference cannot run this shape (models/fusion.py:66 hard-codes 49 positions)."""
+    cfg = O.full_config(embed_dim=512, num_transformer_layers=8, num_answers=2000, num_image_tokens=144)
+    sd = O.init_state_dict(cfg, 29, jitter=True)
+    m = _model("bf16", sd, cfg).eval()
+    images, ids, mask, _ = O.synthetic_batch(256, seed=2026, image_size=384, num_answers=2000)
+    with torch.no_grad():
+        m._ensure_engine().fold_eval = False             # the train-step forward kernels with eval statistics
+        big, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
+        m._engine.fold_eval = True                       # the folded inference path
+        folded, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
+        ref0, _ = O.vqa_forward(images[:3], ids[:3], mask[:3], sd, cfg, training=False)
+        ref1, _ = O.vqa_forward(images[-3:], ids[-3:], mask[-3:], sd, cfg, training=False)
+    torch.cuda.synchronize()
+    assert tuple(big.shape) == (256, 2000) and torch.isfinite(big).all() and torch.isfinite(folded).all()
+    for got in (big, folded):
+        assert (got[:3].cpu() - ref0).abs().max().item() < 5e-2
+        assert (got[-3:].cpu() - ref1).abs().max().item() < 5e-2
+
+
 @pytest.mark.parametrize("dtype,B", [("fp32", 256), ("bf16", 512)])
 def test_full_size_train_step_invariants(dtype, B):
     P = pkg()

@@ -94,10 +94,36 @@ def test_graphed_forward_replays_the_same_logits_for_new_inputs():
             images, ids, _, _ = O.synthetic_batch(3, seed=seed)
             mask = (torch.arange(20)[None, :] < torch.tensor([20, 6, 11])[:, None]).long()
             a = m.forward_graphed(images.to(DEV), ids.to(DEV), mask.to(DEV)).clone()
+            m.graph_inference = False                               # eager launches, kernel by kernel
             b, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
+            m.graph_inference = True                                # the serving route: model(...) under no_grad replays the graph
+            c, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
             torch.cuda.synchronize()
-            assert torch.equal(a, b), seed
+            assert torch.equal(a, b) and torch.equal(a, c), seed
     assert len(m._graphs) == 1
     m.train()
     with pytest.raises(RuntimeError):
         m.forward_graphed(images.to(DEV), ids.to(DEV), mask.to(DEV))
+
+
+def test_graph_cache_is_lru_and_outputs_are_owned_by_the_caller():
+    """api/inference.py:228,296 calls model(...) in eval mode under no_grad at small B: that route replays a captured HIP graph.
+    The shape cache is LRU (a hit refreshes the entry), evicting a graph synchronises first, and forward() hands out a copy of
+    the graph's static output (two results of the same shape must not alias)."""
+    m = _model("bf16")
+    m.graph_max_shapes = 2
+    images, ids, _, _ = O.synthetic_batch(3, seed=41)
+    im, idd = images.to(DEV), ids.to(DEV)
+    with torch.no_grad():
+        o1, _ = m(im[:1], idd[:1], None)
+        o2, _ = m(im[1:2], idd[1:2], None)
+        assert o1.data_ptr() != o2.data_ptr() and not torch.equal(o1, o2)     # same shape, same graph, two owned results
+        k1 = next(iter(m._graphs))
+        m(im[:2], idd[:2], None)                                  # second shape
+        m(im[:1], idd[:1], None)                                  # hit on the first: it becomes the youngest
+        assert list(m._graphs)[-1] == k1
+        m(im[:3], idd[:3], None)                                  # third shape evicts the B=2 graph, not the B=1 one
+        assert k1 in m._graphs and len(m._graphs) == 2
+        o3, _ = m(im[:1], idd[:1], None)
+    torch.cuda.synchronize()
+    assert torch.equal(o3, o1)

@@ -221,3 +221,54 @@ def test_cpu_inputs_fail_loudly():
     images, ids, mask, _ = O.synthetic_batch(1, seed=1)
     with pytest.raises(RuntimeError):
         m(images, ids, mask)
+
+
+def test_two_forwards_then_one_backward_like_the_reference():
+    """Gradient accumulation / loss1 + loss2 (two training forwards, then ONE backward through both) works in the reference
+    (plain autograd); the drop-in keeps a tape per forward, by id.  Checked against autograd of the CPU oracle."""
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0, vocab_size=100, num_answers=10, embed_dim=32)
+    sd = O.init_state_dict(cfg, 7, jitter=True)
+    m = _model(cfg, sd, "fp32").train()
+    b1 = O.synthetic_batch(3, seed=61, image_size=64, seq_len=10, vocab=100, num_answers=10)
+    b2 = O.synthetic_batch(2, seed=62, image_size=64, seq_len=10, vocab=100, num_answers=10)
+    l1, _ = m(b1[0].to(DEV), b1[1].to(DEV), b1[2].to(DEV))
+    l2, _ = m(b2[0].to(DEV), b2[1].to(DEV), b2[2].to(DEV))
+    assert len(m._tapes) == 2
+    loss = torch.nn.functional.cross_entropy(l1, b1[3].to(DEV)) + torch.nn.functional.cross_entropy(l2, b2[3].to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert len(m._tapes) == 0
+    # oracle: same two forwards (BatchNorm buffers advance between them exactly as in the model), summed loss, autograd
+    pnames = set(O.parameter_names(cfg))
+    osd = {k: (v.clone().requires_grad_(True) if k in pnames else v.clone()) for k, v in sd.items()}
+    bufs = {}
+    o1, _ = O.vqa_forward(b1[0], b1[1], b1[2], osd, cfg, True, bufs)
+    o2, _ = O.vqa_forward(b2[0], b2[1], b2[2], osd, cfg, True, bufs)
+    lref = torch.nn.functional.cross_entropy(o1, b1[3]) + torch.nn.functional.cross_entropy(o2, b2[3])
+    lref.backward()
+    assert abs(loss.item() - lref.item()) < 1e-4
+    worst = 0.0
+    for name, p in m.named_parameters():
+        gr = osd[name].grad
+        if gr is None:
+            continue
+        den = float(gr.norm()) + 1e-8
+        worst = max(worst, float((p.grad.cpu() - gr).norm()) / den if den > 1e-6 else 0.0)
+    assert worst < 5e-2, worst
+    # a tape evicted before its backward raises a clear error, it does not KeyError
+    m.max_live_tapes = 1
+    la, _ = m(b1[0].to(DEV), b1[1].to(DEV), b1[2].to(DEV))
+    lb, _ = m(b2[0].to(DEV), b2[1].to(DEV), b2[2].to(DEV))
+    with pytest.raises(RuntimeError, match="max_live_tapes"):
+        (la.sum() + lb.sum()).backward()
+
+
+def test_attention_maps_follow_num_image_tokens():
+    """get_attention_maps at the 144-token extension (BASELINE configs[4] geometry): output_spatial_size is derived (12), not 7."""
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0, vocab_size=100, num_answers=10, embed_dim=64)
+    m = pkg().load_dropin().VQAModel(**cfg, compute_dtype="fp32", num_image_tokens=144).to(DEV).eval()
+    assert m.image_encoder.output_spatial_size == 12
+    images, ids, mask, _ = O.synthetic_batch(2, seed=5, image_size=384, seq_len=10, vocab=100, num_answers=10)
+    with torch.no_grad():
+        maps = m.get_attention_maps(images.to(DEV), ids.to(DEV), mask.to(DEV))
+    assert maps["cross_attention_spatial"].shape == (2, 10, 12, 12)

@@ -141,11 +141,27 @@ def test_cross_entropy_rejects_out_of_range_targets():
     m = _model(cfg, O.init_state_dict(cfg, 1))
     tr = pkg().trainer.HipTrainer(m)
     images, ids, mask, answers = O.synthetic_batch(2, seed=1, image_size=64, seq_len=10, vocab=100, num_answers=10)
+    good = [t.to(DEV) for t in (images, ids, mask, answers)]
+    tr.step(*good)                                                # one ordinary step first: moments are non-zero afterwards
+    torch.cuda.synchronize()
+    p0, m0, v0, t0 = m._flat.detach().clone(), tr.m.clone(), tr.v.clone(), tr.t
+    assert float(m0.abs().max()) > 0
     answers[1] = 10
     tr.step(images.to(DEV), ids.to(DEV), mask.to(DEV), answers.to(DEV))
+    torch.cuda.synchronize()
+    # the reference raises inside the loss, BEFORE optimizer.step (training/train.py:182-208): the model survives the step
+    assert torch.isnan(tr.loss).all() and torch.isnan(tr.G).any()
+    assert torch.equal(m._flat.detach(), p0) and torch.equal(tr.m, m0) and torch.equal(tr.v, v0)
+    assert torch.isfinite(m._flat).all()
     with pytest.raises(IndexError):
         tr.check()
+    assert tr.t == t0                                             # the skipped update does not advance Adam's bias correction
     tr.check()                                                    # counter was reset
+    tr.step(*good)                                                # ... and training continues from intact state
+    torch.cuda.synchronize()
+    assert torch.isfinite(m._flat).all() and torch.isfinite(tr.loss).all() and not torch.equal(m._flat.detach(), p0)
+    with pytest.raises(RuntimeError):
+        tr.step(good[0], good[1], mask, good[3])                  # CPU attention mask: a host pointer must never reach a kernel
     with pytest.raises(RuntimeError):
         tr.step(images, ids.to(DEV), mask.to(DEV), answers.to(DEV))   # CPU tensor: no silent fallback
 
@@ -172,7 +188,7 @@ def test_sumsq_clip_adamw_kernels_match_torch(clip_active, gscale):
         gd = gr.to(DEV)
         L.call("vqa_sumsq", gd.data_ptr(), n, ss.data_ptr())
         L.call("vqa_adamw", pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.01,
-               1.0 - 0.9 ** t, 1.0 - 0.999 ** t, ss.data_ptr(), 1.0, gscale)
+               1.0 - 0.9 ** t, 1.0 - 0.999 ** t, ss.data_ptr(), 1.0, gscale, None, None)
         torch.cuda.synchronize()
         assert abs(float(ss[0].sqrt()) * gscale - float(nrm)) / float(nrm) < 1e-5
         assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6

@@ -96,3 +96,21 @@ def test_torch_custom_ops_are_registered_with_fake_impl():
         assert tuple(out.shape) == (3, 37) and out.dtype == torch.float32
         g = torch.ops.vqa_hip.vqa_backward(out, m._handle, 0)
         assert g.numel() == m._flat.numel()
+
+
+def test_flop_model_reproduces_the_survey_figures_and_prices_the_stress_config():
+    """forward 3.849 GFLOP (conv 3.627 + GEMM/attention 0.222), train step 11.311 GFLOP per pair at the default
+    configuration (measured there with torch's flop counter on the real reference); bench.py prices every configuration, incl.
+    BASELINE configs[4], with this function instead of a constant."""
+    F_ = sub("flops")
+    cfg = O.full_config()
+    f = F_.forward_flops(cfg)
+    assert abs(f["total"] / 1e9 - 3.849) < 2e-3 and abs(f["conv"] / 1e9 - 3.627) < 2e-3 and abs(f["gemm"] / 1e9 - 0.222) < 1e-3
+    assert abs(f["stem"] / 1e6 - 236.0) < 0.1 and f["image_tokens"] == 49
+    assert abs(F_.train_flops(cfg) / 1e9 - 11.311) < 2e-3
+    assert abs(F_.activation_elements(cfg) - 8_433_599) / 8_433_599 < 1e-3           # SURVEY 8(d) "ALGORITHMIC bytes" element count
+    stress = O.full_config(embed_dim=512, num_transformer_layers=8, num_answers=2000)
+    fs = F_.forward_flops(stress, 384, 384, 20)
+    assert fs["image_tokens"] == 144
+    assert abs(fs["conv"] / f["conv"] - (384 / 224) ** 2) < 1e-6                     # the CNN scales with the pixel count exactly
+    assert 35.0 < F_.train_flops(stress, 384, 384, 20) / 1e9 < 35.3

@@ -4,7 +4,7 @@ Import with importlib (the directory name is not a Python identifier):
     pkg = importlib.import_module("visual-question-answering-vqa-system_amd")
 """
 from . import _lib, kernels  # noqa: F401
-from . import layout, engine, trainer  # noqa: F401,E402
+from . import layout, engine, trainer, flops  # noqa: F401,E402
 
 
 def dropin_path() -> str:

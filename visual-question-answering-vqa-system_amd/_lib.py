@@ -85,7 +85,7 @@ SIGNATURES = {
     "vqa_sumsq": [P, LL, P, P],
     "vqa_image_normalize": [P, P, P, I, I, I, F, F, F, F, F, F, P],
     "vqa_pack_tokens": [P, P, P, P, I, I, I, I, I, I, P],
-    "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P],
+    "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P, P, P],
 }
 _RET_LL = {"vqa_wgrad_group_ws", "vqa_spatial_bwd_scratch", "vqa_layernorm_bwd_ws", "vqa_bias_act_bwd_ws"}                       # return a size (long long)
 _NO_STATUS = _RET_LL | {"vqa_wgrad3x3_c128_blocks", "vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
@@ -117,10 +117,18 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional launch hook (kernels.py installs the live profiler of bench.py here): hook(name, args) -> closer | None
+_HOOK = [None]
+
+
 def call(name: str, *args):
     """Invoke a status-returning entry on the current torch stream; raise on non-zero status."""
     fn = getattr(lib(), name)
+    hook = _HOOK[0]
+    done = hook(name, args) if hook is not None else None
     rc = fn(*args, stream())
+    if done is not None:
+        done()
     if rc != 0:
         raise RuntimeError(f"{name} failed with status {rc}" + (" (argument/shape error)" if rc == 1000 else " (hipError_t)"))
 

@@ -46,6 +46,8 @@ class DeviceImageNormalizer:
         out = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
         f = None
         if flip is not None:
+            if flip.numel() != B:
+                raise RuntimeError(f"DeviceImageNormalizer: `flip` must hold one flag per sample ({B}), got {flip.numel()}")
             f = flip.to(device=x.device, dtype=torch.uint8).contiguous()
         self._L.call("vqa_image_normalize", x.data_ptr(), out.data_ptr(), None if f is None else f.data_ptr(), B, H, W,
                      *self.mean, *self.std)

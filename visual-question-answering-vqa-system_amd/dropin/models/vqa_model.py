@@ -48,6 +48,8 @@ def _vqa_forward_op(images: torch.Tensor, token_ids: torch.Tensor, mask: Optiona
     model._last_aux = aux              # aux tensors are detached by construction (side channel, not graph outputs)
     model._tape_seq += 1
     model._tapes[model._tape_seq] = tape
+    while len(model._tapes) > model.max_live_tapes:      # a forward whose backward never ran must not pin its activations forever
+        model._tapes.pop(next(iter(model._tapes)))
     return logits
 
 
@@ -60,7 +62,11 @@ def _(images, token_ids, mask, params, handle, training, want_aux):
 def _vqa_backward_op(dlogits: torch.Tensor, handle: int, tape_id: int) -> torch.Tensor:
     """Returns the FLAT gradient buffer (same layout as the flat parameter buffer); the autograd formula slices it."""
     model = _MODELS[handle]
-    tape = model._tapes.pop(tape_id)
+    tape = model._tapes.pop(tape_id, None)
+    if tape is None:
+        raise RuntimeError(f"vqa_backward: the activations of forward #{tape_id} are gone -- either backward ran twice through it "
+                           f"(the reference needs retain_graph=True for that) or more than max_live_tapes = {model.max_live_tapes} "
+                           "training forwards were issued before its backward (raise VQAModel.max_live_tapes)")
     G = torch.zeros_like(model._flat)
     model._engine.backward(tape, dlogits.contiguous(), G, on_segment=model._on_segment)
     return G
@@ -133,7 +139,7 @@ class VQAModel(nn.Module):
             else:
                 node.register_buffer(leaf, val)
         self.image_encoder.output_channels = 512
-        self.image_encoder.output_spatial_size = 7
+        self.image_encoder.output_spatial_size = int(round(num_image_tokens ** 0.5))   # 7 in the reference (models/cnn_backbone.py:415)
         self.fusion.get_attention_visualization = self._attention_visualization
         self._engine = None
         self._on_segment = None
@@ -191,24 +197,39 @@ class VQAModel(nn.Module):
         maskf = None if attention_mask is None else attention_mask.contiguous().float()
         params = self._param_list()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            self._tapes.clear()                      # a forward whose backward never ran must not pin its activations
+            # tapes are kept by id (gradient accumulation / loss1 + loss2: several forwards, then their backwards), oldest dropped
+            # beyond max_live_tapes
             logits = torch.ops.vqa_hip.vqa_forward(images, token_ids, maskf, params, self._handle, self.training, return_aux)
             aux, self._last_aux = self._last_aux, None
+        elif (self.graph_inference and not self.training and not return_aux and 0 < images.shape[0] <= self.graph_max_batch
+              and not torch.cuda.is_current_stream_capturing()):
+            # the serving case: api/inference.py:228,296 calls model(image, ids, mask) under no_grad at B = 1 ... a few; ~190 launches
+            # of a few microseconds are host-bound there, so the captured HIP graph of this shape is replayed (same kernels, same
+            # logits); the result is copied out of the graph's static buffer so callers own what they get, like the reference
+            logits, aux = self.forward_graphed(images, token_ids, attention_mask).clone(), None
         else:
             logits, aux, _ = eng.forward(images, token_ids, maskf, self.training, return_aux, need_tape=False)
         return (logits, aux) if return_aux else (logits, None)
 
+    def _forward_eager_eval(self, images, token_ids, maskf):
+        logits, _, _ = self._ensure_engine().forward(images, token_ids, maskf, False, False, need_tape=False)
+        return logits
+
     def forward_graphed(self, images: torch.Tensor, token_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Latency mode for serving (api/inference.py:196-323 calls predict at B = 1 ... 64, where ~190 launches of a few
-        microseconds each are host-bound): the eval forward (Conv+BN folded) is captured once per input shape into a HIP graph
-        and replayed; inputs are copied into the graph's static buffers.  Inference only: eval mode, no autograd, logits only."""
+        """Latency mode for serving (api/inference.py:228,296 calls model(...) in eval mode under no_grad at B = 1 ... 64, where
+        ~190 launches of a few microseconds each are host-bound): the eval forward (Conv+BN folded) is captured once per input
+        shape into a HIP graph and replayed; inputs are copied into the graph's static buffers.  Inference only: eval mode, no
+        autograd, logits only.  Returns the graph's STATIC output buffer (valid until the next call with this shape; forward()
+        hands out a copy).  The shape cache is LRU; a graph is only dropped after the stream that replayed it has drained."""
         if self.training:
             raise RuntimeError("forward_graphed is the inference path: call model.eval() first")
         if not images.is_cuda:
             raise RuntimeError("VQAModel (HIP) got CPU inputs; this implementation only runs on an MI355X (no CPU fallback)")
-        key = (tuple(images.shape), tuple(token_ids.shape), attention_mask is not None, self._flat.data_ptr())
-        g = self._graphs.get(key)
-        if g is None:
+        key = (tuple(images.shape), tuple(token_ids.shape), attention_mask is not None, self._flat.data_ptr(), self._ensure_engine().fold_eval)
+        g = self._graphs.pop(key, None)
+        if g is not None:
+            self._graphs[key] = g                    # LRU: a hit moves the shape to the young end
+        else:
             st_img = images.detach().clone().contiguous().float()
             st_ids = token_ids.detach().clone().contiguous().long()
             st_msk = None if attention_mask is None else attention_mask.detach().clone().contiguous().float()
@@ -217,14 +238,16 @@ class VQAModel(nn.Module):
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):                       # warm-up off the default stream, as graph capture requires
                     for _ in range(2):
-                        self.forward(st_img, st_ids, st_msk)
+                        self._forward_eager_eval(st_img, st_ids, st_msk)
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    out, _ = self.forward(st_img, st_ids, st_msk)
+                    out = self._forward_eager_eval(st_img, st_ids, st_msk)
             g = (graph, st_img, st_ids, st_msk, out)
-            while len(self._graphs) >= self.graph_max_shapes:
-                self._graphs.pop(next(iter(self._graphs)))
+            if len(self._graphs) >= self.graph_max_shapes:
+                torch.cuda.synchronize()             # an evicted graph's private pool must outlive its last replay in flight
+                while len(self._graphs) >= self.graph_max_shapes:
+                    self._graphs.pop(next(iter(self._graphs)))
             self._graphs[key] = g
         graph, st_img, st_ids, st_msk, out = g
         st_img.copy_(images); st_ids.copy_(token_ids)
@@ -233,17 +256,15 @@ class VQAModel(nn.Module):
         graph.replay()
         return out
 
-    graph_max_batch = 64          # predict() replays a captured HIP graph up to this batch (the serving case, api/inference.py:196-323)
-    graph_max_shapes = 16         # distinct input shapes kept captured (oldest dropped first)
+    graph_inference = True        # eval-mode no-grad forward()/predict() replay a captured HIP graph up to graph_max_batch
+    graph_max_batch = 64          # (the serving case, api/inference.py:196-323: model(...) at B = 1 ... a few)
+    graph_max_shapes = 16         # distinct input shapes kept captured (least recently used dropped first)
+    max_live_tapes = 4            # training forwards whose backward has not run yet (each pins its activations)
 
     def predict(self, images, token_ids, attention_mask=None, top_k: int = 5):
         self.eval()
         with torch.no_grad():
-            if images.is_cuda and 0 < images.shape[0] <= self.graph_max_batch:
-                # latency mode: ~190 launches of a few microseconds are host-bound at B = 1...64; same kernels, same logits
-                logits = self.forward_graphed(images, token_ids, attention_mask)
-            else:
-                logits, _ = self.forward(images, token_ids, attention_mask)
+            logits, _ = self.forward(images, token_ids, attention_mask)    # (replays the HIP graph of this shape for B <= graph_max_batch)
             probs = F.softmax(logits, dim=-1)
             top_probs, top_indices = probs.topk(top_k, dim=-1)
         return top_indices, top_probs

@@ -29,12 +29,13 @@ class HipEngine:
         self.flat = flat
         self.buf = buffers
         self.dtype = compute_dtype
-        # dropout seeds: (seed_base + step_id) * 4096 + site.  step_id advances on EVERY training forward (so the reference's
-        # unchanged loop model(...) -> loss.backward() -> optimizer.step() draws fresh masks each step); the seeds of a forward
-        # are stored in its tape, so its backward regenerates exactly those masks.  Data-parallel replicas mix their rank in.
+        # dropout seeds: rank << 44 | (seed_base + step_id) << 12 | site.  step_id advances on EVERY training forward (so the
+        # reference's unchanged loop model(...) -> loss.backward() -> optimizer.step() draws fresh masks each step); the seeds of a
+        # forward are stored in its tape, so its backward regenerates exactly those masks.  Data-parallel replicas carry their
+        # rank in disjoint high bits (rank r at step s can never replay rank 0's masks of another step); the rank is read at
+        # the first training forward, not here: the engine is rebuilt by every .to() and may predate init_process_group.
         self.seed_base = 0x5EED
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self.seed_base += 7919 * torch.distributed.get_rank()
+        self.seed_rank = None
         self.step_id = 0
         self.wsrc = flat
         self._wt: Dict[str, torch.Tensor] = {}
@@ -173,7 +174,9 @@ class HipEngine:
 
     def _seed(self):
         self._site += 1
-        return (self.seed_base + self.step_id) * 4096 + self._site
+        if self.seed_rank is None:
+            self.seed_rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        return (self.seed_rank << 44) | (((self.seed_base + self.step_id) & 0xFFFFFFFF) << 12) | self._site
 
     # ------------------------------------------------------------------ small op helpers
     def _bn_coef(self, prefix, stats, mt, C, count, training):

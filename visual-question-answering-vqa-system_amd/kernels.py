@@ -17,8 +17,67 @@ from ._lib import call, dt, ptr
 LOADER_NHWC, LOADER_STEM = 0, 1
 
 # Optional live profiling (bench.py): when PROFILE is a list, igemm/wgrad bracket their launch with events on the
-# launch stream and append (kernel symbol, algorithmic FLOPs, start event, end event).
+# launch stream and append (kernel symbol, algorithmic FLOPs, start event, end event, algorithmic bytes).
 PROFILE = None
+
+# HBM-bound entries (no FLOPs worth counting): algorithmic bytes of one call from its C-ABI argument list -- the tensors the op
+# must read and write once; recorded as ("hbm:<class>:<entry>", 0, e0, e1, bytes) while PROFILE is a list.
+_ES = lambda d: 2 if d else 4          # element size of the compute dtype argument (0 = f32, 1 = bf16)
+_P = lambda p: 1 if p else 0           # optional operand present
+HBM_BYTES = {
+    # BatchNorm passes (A3): statistics finalize reads the slab; apply reads y (+ residual) and writes out; backward reduce reads
+    # dout, y (+ activation, + shortcut y); backward apply reads dout, y (+ activation) and writes dy (+ shortcut: y2 in, dy2 out)
+    "vqa_bn_stats_finalize": ("bn", lambda a: a[1] * a[2] * 2 * 4 + a[2] * 4 * 8),
+    "vqa_bn_apply": ("bn", lambda a: a[6] * _ES(a[0]) * (2 + _P(a[3]))),
+    "vqa_bn_bwd_reduce": ("bn", lambda a: a[8] * a[9] * _ES(a[0]) * (2 + _P(a[2]) + _P(a[5]))),
+    "vqa_bn_bwd_finalize": ("bn", lambda a: a[1] * a[2] * 3 * 4),
+    "vqa_bn_bwd_apply": ("bn", lambda a: a[9] * _ES(a[0]) * (3 + _P(a[2]) + 2 * _P(a[6]))),
+    "vqa_stem_pool_fwd": ("stem_pool", lambda a: a[5] * a[6] * a[7] * a[8] * _ES(a[0])
+                          + a[5] * ((a[6] - 1) // 2 + 1) * ((a[7] - 1) // 2 + 1) * a[8] * (_ES(a[0]) + 1)),
+    # SE / spatial attention (A4, A5): pool read + scale read + write forward; dout, x in and dx out backward
+    "vqa_se_fwd": ("se_spatial", lambda a: 3 * a[8] * a[9] * a[10] * _ES(a[0])),
+    "vqa_se_bwd": ("se_spatial", lambda a: 3 * a[12] * a[13] * a[14] * _ES(a[0])),
+    "vqa_spatial_fwd": ("se_spatial", lambda a: 3 * a[7] * a[8] * a[9] * a[10] * _ES(a[0])),
+    "vqa_spatial_bwd": ("se_spatial", lambda a: 3 * a[10] * a[11] * a[12] * a[13] * _ES(a[0])),
+    # token side: LayerNorm, bias / activation backward, pools, gate, adds, embedding, attention (its FLOPs are tiny: latency class)
+    "vqa_layernorm_fwd": ("token", lambda a: 2 * a[6] * a[7] * _ES(a[0])),
+    "vqa_layernorm_bwd": ("token", lambda a: (3 + _P(a[5])) * a[9] * a[10] * _ES(a[0])),
+    "vqa_bias_act_bwd": ("token", lambda a: a[5] * a[6] * _ES(a[0]) * (1 + _P(a[2]) + _P(a[3]))),
+    "vqa_add": ("token", lambda a: 3 * a[4] * _ES(a[0])),
+    "vqa_embed_fwd": ("token", lambda a: a[5] * a[7] * (4 + _ES(a[0]))),
+    "vqa_embed_bwd": ("token", lambda a: a[4] * a[5] * _ES(a[0]) + a[6] * a[5] * 4),
+    "vqa_masked_pool_fwd": ("token", lambda a: a[6] * a[7] * a[8] * _ES(a[0])),
+    "vqa_masked_pool_bwd": ("token", lambda a: a[7] * a[8] * a[9] * _ES(a[0])),
+    "vqa_attention_fwd_mfma": ("attention", lambda a: (a[10] * (a[12] + 2 * a[13]) * a[9] + a[10] * a[12] * a[9]) * 2 + a[10] * a[11] * a[12] * a[13] * 4),
+    "vqa_attention_bwd_mfma": ("attention", lambda a: 2 * (a[15] * (a[17] + 2 * a[18]) * a[1]) * 2 + a[15] * a[17] * a[1] * 2 + a[15] * a[16] * a[17] * a[18] * 4),
+    "vqa_attention_fwd": ("attention", lambda a: (a[11] * (a[13] + 2 * a[14]) * a[10] + a[11] * a[13] * a[10]) * _ES(a[0]) + a[11] * a[12] * a[13] * a[14] * 4),
+    "vqa_attention_bwd": ("attention", lambda a: 2 * (a[16] * (a[18] + 2 * a[19]) * a[2]) * _ES(a[0]) + a[16] * a[18] * a[2] * _ES(a[0]) + a[16] * a[17] * a[18] * a[19] * 4),
+    "vqa_cross_entropy": ("token", lambda a: a[6] * a[7] * (_ES(a[0]) + 4)),
+    # weight staging and the optimizer tail (H, N1): cast of the flat buffer, packed data-gradient operands, sum of squares, AdamW
+    "vqa_convert": ("optimizer", lambda a: a[4] * (_ES(a[0]) + _ES(a[1]))),
+    "vqa_sumsq": ("optimizer", lambda a: a[1] * 4),
+    "vqa_adamw": ("optimizer", lambda a: a[4] * 4 * 7),
+}
+
+
+def _hbm_hook(name, args):
+    if PROFILE is None:
+        return None
+    ent = HBM_BYTES.get(name)
+    if ent is None:
+        return None
+    cls, fn = ent
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    prof = PROFILE
+
+    def done():
+        e1.record()
+        prof.append((f"hbm:{cls}:{name[4:]}", 0.0, e0, e1, float(fn(args))))
+    return done
+
+
+L._HOOK[0] = _hbm_hook
 
 
 def igemm_variant(dtype, loader, M, N, Kw, geom) -> int:

@@ -22,27 +22,25 @@ class GradBucketReducer:
     """Sum-all-reduce of contiguous gradient buckets, issued bucket by bucket while backward is still running.
     Device-agnostic (CUDA tensors: side stream + events, RCCL; CPU tensors: gloo) so the N>1 logic is testable on CPU."""
 
-    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, overlap=True):
+    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, overlap=True, force=False):
+        """force: run the whole bucket choreography (communication stream, events, async all-reduce per bucket, waits) even in a
+        world of ONE rank -- a single-rank RCCL group executes the same code path an 8-GPU job does, so the one-GPU test box can
+        run it for real (tests/test_gpu_nccl_world1.py, bench.py --force-reducer); needs an initialised process group."""
         self.G = flat_grad
         self.buckets = list(buckets)
         self._range = {name: (lo, hi) for name, lo, hi in self.buckets}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        if force and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GradBucketReducer(force=True) needs an initialised torch.distributed process group")
+        self.active = self.world > 1 or force
         self.overlap = overlap and flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream() if (self.world > 1 and self.overlap) else None
+        self.comm_stream = torch.cuda.Stream() if (self.active and self.overlap) else None
         self._works: List = []
         self.issued: List[str] = []
+        self.bytes_reduced = 0
 
-    def on_segment(self, name: str, events=()):
-        """`events`: HIP events after which every gradient kernel of this segment has been enqueued-and-ordered (the engine
-        records one on each stream that wrote the bucket: the data-gradient stream and the weight-gradient side stream).
-        Only the COMMUNICATION stream waits for them -- the compute streams are never joined here, so the data-gradient chain
-        keeps running ahead of the weight gradients exactly as in the 1-GPU step."""
-        if self.world == 1 or name not in self._range:
-            return
-        lo, hi = self._range[name]
-        bucket = self.G[lo:hi]
-        self.issued.append(name)
+    def _issue(self, tensor, events=()):
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record()
@@ -50,13 +48,31 @@ class GradBucketReducer:
                 self.comm_stream.wait_event(ev)
                 for e in events:
                     self.comm_stream.wait_event(e)
-                self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
-            if self.G.is_cuda:
+            if tensor.is_cuda:
                 cur = torch.cuda.current_stream()
                 for e in events:
                     cur.wait_event(e)
-            self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self._works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self.bytes_reduced += tensor.numel() * tensor.element_size()
+
+    def reduce_aux(self, tensor: torch.Tensor):
+        """Sum a small side tensor (the per-step bad-target counter) over the ranks; ordered after everything enqueued so far on
+        the current stream, waited for in finish() with the gradient buckets."""
+        if self.active:
+            self._issue(tensor)
+
+    def on_segment(self, name: str, events=()):
+        """`events`: HIP events after which every gradient kernel of this segment has been enqueued-and-ordered (the engine
+        records one on each stream that wrote the bucket: the data-gradient stream and the weight-gradient side stream).
+        Only the COMMUNICATION stream waits for them -- the compute streams are never joined here, so the data-gradient chain
+        keeps running ahead of the weight gradients exactly as in the 1-GPU step."""
+        if not self.active or name not in self._range:
+            return
+        lo, hi = self._range[name]
+        self.issued.append(name)
+        self._issue(self.G[lo:hi], events)
 
     def finish(self):
         """Make the current stream (or the host, for gloo) wait for every bucket; returns the 1/world gradient scale."""
@@ -69,7 +85,7 @@ class GradBucketReducer:
 
 class HipTrainer:
     def __init__(self, model, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
-                 process_group=None, overlap=True):
+                 process_group=None, overlap=True, force_reducer=False):
         self.model = model
         self.engine = model._ensure_engine()
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_grad_norm
@@ -78,11 +94,16 @@ class HipTrainer:
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
         self.sumsq = torch.zeros(1 + 2048, device=flat.device, dtype=torch.float32)   # [0] = sum of squares, rest: block partials
-        self.loss = torch.zeros(1, device=flat.device, dtype=torch.float32)
-        self.bad_targets = torch.zeros(1, device=flat.device, dtype=torch.int32)   # rows whose target was outside [0, num_answers)
+        # one 8-byte scratch zeroed by ONE launch per step: [0] the loss (float32 view), [1] rows of THIS step whose target was
+        # outside [0, num_answers) (int32; all-zero bits are 0.0f and 0).  The AdamW kernel skips the update when [1] != 0 and
+        # accumulates {rows, steps} into `bad_targets` for check().
+        self._scal = torch.zeros(2, device=flat.device, dtype=torch.int32)
+        self.loss = self._scal[0:1].view(torch.float32)
+        self.bad_step = self._scal[1:2]
+        self.bad_targets = torch.zeros(2, device=flat.device, dtype=torch.int32)   # {rows out of range, steps skipped} since the last check()
         self.t = 0
         self.buckets = LY.bucket_ranges(model._entries)
-        self.reducer = GradBucketReducer(self.G, self.buckets, process_group, overlap)
+        self.reducer = GradBucketReducer(self.G, self.buckets, process_group, overlap, force=force_reducer)
         self.world = self.reducer.world
 
     def step(self, images, token_ids, attention_mask, targets, metrics=None):
@@ -96,28 +117,33 @@ class HipTrainer:
         if images.dim() != 4 or images.shape[1] != 3 or token_ids.dim() != 2 or token_ids.shape[0] != images.shape[0] \
                 or targets.shape != (images.shape[0],):
             raise RuntimeError("HipTrainer.step: expected images [B,3,H,W], token_ids [B,L], targets [B]")
+        if attention_mask is not None and not (isinstance(attention_mask, torch.Tensor) and attention_mask.device == dev
+                                               and attention_mask.shape == token_ids.shape):
+            raise RuntimeError(f"HipTrainer.step: `attention_mask` must be a [B,L] tensor on {dev} (or None)")
         # the kernels read raw pointers: enforce the dtypes / contiguity VQAModel.forward enforces (vqa_model.py drop-in)
         images = images.contiguous().float()
         token_ids = token_ids.contiguous().long()
         targets = targets.contiguous().long()
         self.G.zero_()
-        self.loss.zero_()
+        self._scal.zero_()
         maskf = None if attention_mask is None else attention_mask.contiguous().float()
         logits_f, _, tape = eng.forward(images, token_ids, maskf, True, False, need_tape=True)
         B, N = logits_f.shape
         dlogits = torch.empty((B, N), device=images.device, dtype=torch.float32)
         ce_ws = torch.empty((B,), device=images.device, dtype=torch.float32)
-        call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0, ptr(self.bad_targets),
+        call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0, ptr(self.bad_step),
              ptr(ce_ws))                                   # per-row loss terms, folded in row order (bit-reproducible)
+        self.reducer.reduce_aux(self.bad_step)             # every rank must skip the update of a step ANY rank rejects
         if metrics is not None:
             metrics.update(logits_f, targets)
-        eng.backward(tape, dlogits, self.G, on_segment=self.reducer.on_segment if self.world > 1 else None)
+        eng.backward(tape, dlogits, self.G, on_segment=self.reducer.on_segment if self.reducer.active else None)
         gscale = self.reducer.finish()
         call("vqa_sumsq", ptr(self.G), self.G.numel(), ptr(self.sumsq))
         self.t += 1
         b1, b2 = self.betas
         call("vqa_adamw", ptr(self.model._flat), ptr(self.G), ptr(self.m), ptr(self.v), self.G.numel(), self.lr, b1, b2, self.eps,
-             self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, ptr(self.sumsq), float(self.max_norm), gscale)
+             self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, ptr(self.sumsq), float(self.max_norm), gscale,
+             ptr(self.bad_step), ptr(self.bad_targets))
         return self.loss, logits_f
 
     def grad_norm(self) -> torch.Tensor:
@@ -126,7 +152,9 @@ class HipTrainer:
     def check(self):
         """Host-side error check (one sync; call it per logging interval, not per step): raises like nn.CrossEntropyLoss does
         (training/train.py:120) if any step since the last check saw a target outside [0, num_answers)."""
-        n = int(self.bad_targets.item())
+        n, skipped = (int(x) for x in self.bad_targets.tolist())
         if n:
             self.bad_targets.zero_()
-            raise IndexError(f"{n} target(s) out of range [0, {self.model.num_answers}) since the last check (loss and gradients are NaN)")
+            self.t -= skipped                     # the skipped updates never happened: keep Adam's bias correction in step
+            raise IndexError(f"{n} target(s) out of range [0, {self.model.num_answers}) since the last check: {skipped} step(s) were "
+                             "skipped on every rank (parameters and optimizer state untouched; that step's loss and gradients are NaN)")
