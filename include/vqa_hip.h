@@ -214,9 +214,21 @@ int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float l
 /* ---- input pipeline on the GPU -----------------------------------------------------------------
  * vqa_image_normalize: torchvision ToTensor + Normalize of data/preprocess.py:34-35,117-121 -- uint8 HWC [B][H][W][3] ->
  * float32 NCHW, (u/255 - mean[c]) / std[c] in torch's operation order (bit-identical), optional per-sample horizontal flip
- * (flip[b] != 0; RandomHorizontalFlip, data/preprocess.py:73).  W % 4 == 0.  Resize / ColorJitter (PIL) stay on the host.
+ * (flip[b] != 0; RandomHorizontalFlip, data/preprocess.py:73).  W % 4 == 0.  ColorJitter (PIL) stays on the host.
  * vqa_pack_tokens: Tokenizer.encode (utils/tokenizer.py:196-250) for a batch -- ragged vocabulary indices words[offsets[b] ..
  * offsets[b+1]) -> ids / mask int64 [B][L]: START + words + END, truncated to L with END forced onto the last slot, PAD after. */
+/* vqa_image_resize: transforms.Resize((RH, RW)) of a PIL image (data/preprocess.py:70,90,118; api/inference.py:140-170), i.e.
+ * PIL.Image.resize(BILINEAR) -- Pillow Resample.c restated bit-exactly (double-precision triangle weights scaled by the down-scale
+ * factor, 22-bit fixed point, horizontal pass to a uint8 intermediate, then vertical) -- for a RAGGED batch: image i is uint8 HWC
+ * [H[i]][W[i]][3] at in + in_off[i].  Optional RandomCrop window (crop_yx[2i], crop_yx[2i+1]) of size OH x OW inside the resized
+ * RH x RW image (data/preprocess.py:70-71; NULL: no crop, then OH == RH and OW == RW) and per-sample horizontal flip (device
+ * uint8[n] or NULL).  Outputs (either may be NULL): out_u8 [n][OH][OW][3] (what PIL returns) and out_nchw float32 [n][3][OH][OW] =
+ * ToTensor + Normalize of it.  in_off / H / W / crop_yx are HOST arrays (they become kernel arguments, 32 images per launch);
+ * `ws` is device scratch of vqa_image_resize_ws() bytes (coefficient tables + the horizontal intermediates). */
+long long vqa_image_resize_ws(int n, const int* H, const int* W, int RH, int RW, int OW);
+int vqa_image_resize(const uint8_t* in, const long long* in_off, const int* H, const int* W, const int* crop_yx, int n, int RH, int RW,
+                     int OH, int OW, uint8_t* out_u8, float* out_nchw, const uint8_t* flip, float mean0, float mean1, float mean2,
+                     float std0, float std1, float std2, void* ws, long long ws_bytes, hipStream_t stream);
 int vqa_image_normalize(const uint8_t* in_hwc, float* out_nchw, const uint8_t* flip, int B, int H, int W, float mean0, float mean1,
                         float mean2, float std0, float std1, float std2, hipStream_t stream);
 int vqa_pack_tokens(const int* words, const long long* offsets, long long* ids, long long* mask, int B, int L, int add_special,

@@ -55,3 +55,106 @@ def to_tensor_normalize(img_u8_hwc: torch.Tensor, flip=None) -> torch.Tensor:
     mean = torch.as_tensor(IMAGENET_MEAN, dtype=torch.float32)[None, :, None, None]
     std = torch.as_tensor(IMAGENET_STD, dtype=torch.float32)[None, :, None, None]
     return t.sub(mean).div(std)
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# transforms.Resize((224, 224)) on a PIL image (data/preprocess.py:90,118; api/inference.py:140-170) is
+# PIL.Image.resize(size, BILINEAR).  The algorithm lives in Pillow (third-party, not in /root/reference): src/libImaging/Resample.c of
+# the Pillow pinned by this image (12.2.0): precompute_coeffs (double precision, support scaled by the down-scale factor),
+# normalize_coeffs_8bpc (fixed point, PRECISION_BITS = 32 - 8 - 2), ImagingResampleHorizontal_8bpc then ImagingResampleVertical_8bpc
+# with a uint8-ROUNDED intermediate image, each pass skipped when that axis keeps its size.  Restated here in numpy integer
+# arithmetic and PINNED bit-exactly by tests/golden/resize_pil.npz, written by the real PIL.Image.resize in this container
+# (tests/golden/make_golden.py gen_resize).
+# --------------------------------------------------------------------------------------------------------------------------
+PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size: int, out_size: int):
+    """precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter (support 1.0) over the whole axis (box = 0 .. in_size).
+    Returns (xmin int32 [out], xn int32 [out], k int32 [out][ksize])."""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    xmin = np.zeros(out_size, np.int32); xn = np.zeros(out_size, np.int32); kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        lo = int(center - support + 0.5)                     # C (int) cast: truncation toward zero
+        lo = max(lo, 0)
+        hi = int(center + support + 0.5)
+        hi = min(hi, in_size)
+        n = hi - lo
+        w = np.zeros(n, np.float64)
+        ww = 0.0
+        for x in range(n):
+            a = (x + lo - center + 0.5) * ss
+            a = -a if a < 0.0 else a
+            w[x] = 1.0 - a if a < 1.0 else 0.0
+            ww += w[x]
+        if ww != 0.0:
+            w = w / ww
+        for x in range(n):
+            v = w[x] * (1 << PRECISION_BITS)
+            kk[xx, x] = int(-0.5 + v) if w[x] < 0 else int(0.5 + v)
+        xmin[xx], xn[xx] = lo, n
+    return xmin, xn, kk
+
+
+def _resample_axis0(img: np.ndarray, out_size: int) -> np.ndarray:
+    """One 8bpc pass along axis 0 of uint8 [n][...]: clip8((1 << (PRECISION_BITS-1)) + sum k*pixel >> PRECISION_BITS)."""
+    xmin, xn, kk = pil_bilinear_coeffs(img.shape[0], out_size)
+    out = np.empty((out_size,) + img.shape[1:], np.uint8)
+    src = img.astype(np.int64)
+    for o in range(out_size):
+        acc = np.full(img.shape[1:], 1 << (PRECISION_BITS - 1), np.int64)
+        for x in range(int(xn[o])):
+            acc += src[xmin[o] + x] * int(kk[o, x])
+        out[o] = np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
+    return out
+
+
+def pil_resize_bilinear(img_u8_hwc: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """PIL.Image.fromarray(img).resize((out_w, out_h), Image.BILINEAR) for a uint8 [H][W][C] array: horizontal pass first (uint8
+    intermediate), then vertical; a pass whose axis already has the target size is skipped (ImagingResample)."""
+    x = np.ascontiguousarray(img_u8_hwc)
+    H, W = x.shape[:2]
+    if W != out_w:
+        x = np.swapaxes(_resample_axis0(np.swapaxes(x, 0, 1), out_w), 0, 1)
+    if H != out_h:
+        x = _resample_axis0(x, out_h)
+    return np.ascontiguousarray(x)
+
+
+def pattern_image(H: int, W: int, seed: int, noise_bits: int = 5) -> np.ndarray:
+    """Deterministic uint8 [H][W][3] test image from INTEGER arithmetic only (identical on every platform / numpy version, so the
+    fixture generator and the tests rebuild the same inputs without storing them): a wrapped gradient with per-channel slopes plus
+    splitmix64 noise of `noise_bits` bits (8: pure noise)."""
+    y, x, c = np.meshgrid(np.arange(H, dtype=np.uint64), np.arange(W, dtype=np.uint64), np.arange(3, dtype=np.uint64), indexing="ij")
+    idx = (y * np.uint64(W) + x) * np.uint64(3) + c
+    with np.errstate(over="ignore"):
+        z = idx + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    noise = (z >> np.uint64(64 - noise_bits)).astype(np.int64) if noise_bits else np.zeros_like(idx, dtype=np.int64)
+    base = (y.astype(np.int64) * (3 + seed % 5) + x.astype(np.int64) * (2 + c.astype(np.int64)) + c.astype(np.int64) * 85) % 256
+    if noise_bits >= 8:
+        return (noise & 255).astype(np.uint8)
+    return ((base + noise) % 256).astype(np.uint8)
+
+
+# the cases of tests/golden/resize_pil.npz: (tag, H, W, resize target, crop size | None, crop origin (y, x), flip, seed, noise bits)
+RESIZE_CASES = [
+    ("down_both", 480, 640, 224, None, (0, 0), 0, 1, 5),
+    ("up_both", 100, 150, 224, None, (0, 0), 0, 2, 5),
+    ("identity", 96, 96, 96, None, (0, 0), 0, 3, 8),
+    ("h_only", 224, 300, 224, None, (0, 0), 0, 4, 5),
+    ("v_only", 500, 224, 224, None, (0, 0), 0, 5, 5),
+    ("extreme_aspect", 37, 1000, 96, None, (0, 0), 0, 6, 8),
+    ("aug_crop_flip", 333, 500, 256, 224, (16, 5), 1, 7, 5),
+    ("one_pixel", 1, 1, 224, None, (0, 0), 0, 8, 8),
+    ("off_by_one", 97, 95, 96, None, (0, 0), 0, 9, 8),
+    ("noise_down3x", 300, 290, 96, None, (0, 0), 1, 10, 8),
+    ("noise_up", 40, 56, 96, None, (0, 0), 0, 11, 8),
+]

@@ -200,7 +200,39 @@ def gen_input():
     print("input_pipeline", out["ids_l20"].shape, int(out["mask_l20"].sum()), "vocab", len(json.loads(str(out["vocab_l20"]))))
 
 
+def gen_resize():
+    """transforms.Resize((S, S)) on a PIL image is PIL.Image.resize((S, S), BILINEAR) (torchvision's functional resize calls exactly
+    that for PIL inputs; torchvision itself is absent here, PIL 12.2.0 is present): data/preprocess.py:70,90,118, api/inference.py:
+    140-170.  Outputs of the REAL PIL on integer-pattern images (oracle.input_oracle.pattern_image: rebuilt, not stored), the
+    RandomCrop window / horizontal flip of the augmented pipeline as plain indexing of PIL's output, and ToTensor + Normalize of the
+    actual PIL image via np.array (torchvision's ToTensor: from_numpy(np.array(pic)) -> permute -> float / 255; Normalize: sub_ mean, div_ std)."""
+    import hashlib
+    from PIL import Image
+    from oracle import input_oracle as IO
+    out = {"pil_version": np.array(__import__("PIL").__version__)}
+    mean = torch.as_tensor(IO.IMAGENET_MEAN, dtype=torch.float32)[:, None, None]
+    std = torch.as_tensor(IO.IMAGENET_STD, dtype=torch.float32)[:, None, None]
+    for tag, H, W, S, crop, (cy, cx), flip, seed, nb in IO.RESIZE_CASES:
+        img = IO.pattern_image(H, W, seed, nb)
+        pil = Image.fromarray(img, mode="RGB").resize((S, S), Image.BILINEAR)
+        if crop:
+            pil = pil.crop((cx, cy, cx + crop, cy + crop))                       # RandomCrop: F.crop -> img.crop((left, top, right, bottom))
+        if flip:
+            pil = pil.transpose(Image.FLIP_LEFT_RIGHT)                           # RandomHorizontalFlip: F.hflip
+        arr = np.array(pil, copy=True)                                           # ToTensor starts here
+        t = torch.from_numpy(arr).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+        t = t.sub_(mean).div_(std)                                               # Normalize
+        out[f"{tag}_u8"] = arr
+        out[f"{tag}_sha"] = np.array(hashlib.sha256(img.tobytes()).hexdigest())
+        # the float tensor is a pure function of arr; keep a thin slice of it (rows 0, 111, last) instead of 600 KB per case
+        out[f"{tag}_norm_rows"] = t[:, [0, t.shape[1] // 2, t.shape[1] - 1], :].numpy()
+    np.savez_compressed(os.path.join(OUT, "resize_pil.npz"), **out)
+    print("resize_pil", len(IO.RESIZE_CASES), "cases", os.path.getsize(os.path.join(OUT, "resize_pil.npz")), "bytes")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "resize":
+        gen_resize(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         gen_metrics(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "input":
@@ -212,3 +244,4 @@ if __name__ == "__main__":
     gen_overfit()
     gen_metrics()
     gen_input()
+    gen_resize()

@@ -1,7 +1,7 @@
 """GPU: the device half of the input pipeline through the C ABI.
   vqa_pack_tokens      == the REAL reference Tokenizer's batch_encode (golden fixture), bit-exact (index work)
-  vqa_image_normalize  == ToTensor + Normalize restated with torch (oracle.input_oracle; torchvision is absent in the build
-                          container, so this half is pinned to the restatement only), bit-exact, at 224x224 and with flips
+  vqa_image_normalize  == ToTensor + Normalize restated with torch (oracle.input_oracle), bit-exact, at 224x224 and with flips
+  vqa_image_resize     == PIL.Image.resize(BILINEAR) + ToTensor + Normalize, pinned by outputs of the REAL PIL (resize_pil.npz)
 and the drop-in surfaces built on them (Tokenizer.batch_encode_device, DeviceImageNormalizer, gpu_collate_fn) feeding the model."""
 import json
 import os
@@ -92,3 +92,74 @@ def test_gpu_collate_feeds_the_model():
         ref, _ = O.vqa_forward(IO.to_tensor_normalize(torch.stack([torch.as_tensor(it[0]) for it in items])), batch["token_ids"].cpu(),
                                batch["attention_mask"].cpu(), O.init_state_dict(cfg, 3), cfg, training=False)
     assert (logits.cpu() - ref).abs().max().item() < 1e-3
+
+
+# ---- Resize on the GPU: vqa_image_resize == PIL.Image.resize(BILINEAR), bit for bit ----
+@pytest.fixture(scope="module")
+def rgold(golden_dir):
+    return np.load(os.path.join(golden_dir, "resize_pil.npz"))
+
+
+@pytest.mark.parametrize("case", IO.RESIZE_CASES, ids=[c[0] for c in IO.RESIZE_CASES])
+def test_device_resize_bit_exact_against_pil(rgold, case):
+    """data/preprocess.py:70,90,118 / api/inference.py:140-170: Resize((S, S)) [+ RandomCrop window + flip] + ToTensor + Normalize.
+    uint8 output == what the real PIL produced (golden), float output == ToTensor + Normalize of it, every value bit for bit."""
+    tag, H, W, S, crop, (cy, cx), flip, seed, nb = case
+    P = pkg().load_dropin_preprocess()
+    img = IO.pattern_image(H, W, seed, nb)
+    rz = P.DeviceImageResizer(size=S, crop=crop)
+    fl = torch.tensor([bool(flip)]) if flip else None
+    out, u8 = rz([img], crop_yx=[(cy, cx)] if crop else None, flip=fl, return_u8=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(u8[0].cpu().numpy(), rgold[f"{tag}_u8"])
+    ref = IO.to_tensor_normalize(torch.from_numpy(rgold[f"{tag}_u8"])[None])
+    assert torch.equal(out.cpu(), ref)
+    rows = out[0].cpu()[:, [0, out.shape[2] // 2, out.shape[2] - 1], :].numpy()
+    assert np.array_equal(rows, rgold[f"{tag}_norm_rows"])
+
+
+def test_device_resize_ragged_batch_matches_oracle_and_feeds_the_model():
+    """A ragged batch (70 images of different sizes: three launch groups of 32, mixed up- / down-scaling, images that keep one
+    axis) in ONE call against the numpy restatement of Pillow (itself pinned to PIL by the golden cases), then through
+    gpu_collate_fn(resizer=...) into the model."""
+    P = pkg().load_dropin_preprocess()
+    rng = np.random.default_rng(3)
+    sizes = [(int(rng.integers(20, 400)), int(rng.integers(20, 400))) for _ in range(66)] + [(224, 100), (90, 224), (224, 224), (1, 7)]
+    imgs = [IO.pattern_image(h, w, 100 + i, 8 if i % 3 == 0 else 5) for i, (h, w) in enumerate(sizes)]
+    flip = torch.tensor([i % 4 == 1 for i in range(len(imgs))])
+    rz = P.DeviceImageResizer(size=224)
+    out, u8 = rz(imgs, flip=flip, return_u8=True)
+    torch.cuda.synchronize()
+    assert out.shape == (70, 3, 224, 224) and u8.shape == (70, 224, 224, 3)
+    got = u8.cpu().numpy()
+    for i, im in enumerate(imgs):
+        ref = IO.pil_resize_bilinear(im, 224, 224)
+        if flip[i]:
+            ref = ref[:, ::-1]
+        assert np.array_equal(got[i], ref), (i, sizes[i])
+    assert torch.equal(out.cpu(), IO.to_tensor_normalize(torch.from_numpy(got)))
+    # augmented pipeline: Resize(256) -> RandomCrop(224) -> flip; origins drawn by the collate function, every value checked
+    rz2 = P.DeviceImageResizer(size=256, crop=224)
+    yx = [(int(rng.integers(0, 33)), int(rng.integers(0, 33))) for _ in imgs[:9]]
+    out2, u82 = rz2(imgs[:9], crop_yx=yx, flip=flip[:9], return_u8=True)
+    for i in range(9):
+        ref = IO.pil_resize_bilinear(imgs[i], 256, 256)[yx[i][0]: yx[i][0] + 224, yx[i][1]: yx[i][1] + 224]
+        if flip[i]:
+            ref = ref[:, ::-1]
+        assert np.array_equal(u82[i].cpu().numpy(), ref), i
+    with pytest.raises(RuntimeError):
+        rz2(imgs[:2])                                               # a crop needs its origins
+    with pytest.raises(RuntimeError):
+        rz([imgs[0].astype(np.float32)])
+    with pytest.raises(RuntimeError):
+        rz(imgs[:2], flip=torch.tensor([True]))                     # one flag per image
+    # the collate route: decoded images of any size -> model-ready batch
+    T = pkg().load_dropin_tokenizer()
+    tok = T.Tokenizer(max_length=20, vocab_size=100)
+    qs = ["what color is the cat", "how many dogs", "is it raining?"]
+    tok.build_vocab(qs, min_freq=1)
+    items = [(imgs[i],) + tuple(tok.encode(q)) + (i,) for i, q in enumerate(qs)]
+    batch = P.gpu_collate_fn(items, resizer=rz)
+    assert batch["images"].shape == (3, 3, 224, 224) and batch["images"].is_cuda
+    ref3 = IO.to_tensor_normalize(torch.from_numpy(np.stack([IO.pil_resize_bilinear(imgs[i], 224, 224) for i in range(3)])))
+    assert torch.equal(batch["images"].cpu(), ref3)

@@ -59,3 +59,51 @@ def test_image_oracle_matches_fixture_and_formula(gold):
     # spot values: (u/255 - mean) / std
     assert abs(float(out[0, 0, 0, 0]) - (0.0 - 0.485) / 0.229) < 1e-6
     assert abs(float(out[0, 1, 0, 0]) - (1.0 - 0.456) / 0.224) < 1e-6
+
+
+# ---- image half: Resize (PIL BILINEAR) + ToTensor + Normalize, pinned by the REAL PIL (tests/golden/resize_pil.npz) ----
+import hashlib  # noqa: E402
+
+import torch  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def rgold(golden_dir):
+    return np.load(os.path.join(golden_dir, "resize_pil.npz"))
+
+
+def _expected_from_oracle(case):
+    tag, H, W, S, crop, (cy, cx), flip, seed, nb = case
+    img = IO.pattern_image(H, W, seed, nb)
+    out = IO.pil_resize_bilinear(img, S, S)
+    if crop:
+        out = out[cy: cy + crop, cx: cx + crop]
+    if flip:
+        out = out[:, ::-1]
+    return img, np.ascontiguousarray(out)
+
+
+@pytest.mark.parametrize("case", IO.RESIZE_CASES, ids=[c[0] for c in IO.RESIZE_CASES])
+def test_oracle_resize_is_bit_exact_against_pil(rgold, case):
+    """oracle.input_oracle.pil_resize_bilinear (numpy restatement of Pillow's Resample.c) == the uint8 image the real
+    PIL.Image.resize(BILINEAR) produced (+ crop / flip as indexing); ToTensor + Normalize restated == the rows stored from the
+    real np.array(pil) -> torch pipeline.  Down-, up-scaling, one axis only, identity, 1x1, extreme aspect ratio, pure noise."""
+    tag = case[0]
+    img, got = _expected_from_oracle(case)
+    assert hashlib.sha256(img.tobytes()).hexdigest() == str(rgold[f"{tag}_sha"])      # the rebuilt input IS the fixture's input
+    assert np.array_equal(got, rgold[f"{tag}_u8"])
+    t = IO.to_tensor_normalize(torch.from_numpy(got)[None])[0]
+    rows = t[:, [0, t.shape[1] // 2, t.shape[1] - 1], :].numpy()
+    assert np.array_equal(rows, rgold[f"{tag}_norm_rows"])
+
+
+def test_pil_coefficients_known_answers():
+    """precompute_coeffs / normalize_coeffs_8bpc known answers: 2x down-scale = the 4-tap triangle {1,3,3,1}/8 in 22-bit fixed
+    point, clipped windows at the borders renormalise to sum 1.0, identity scale degenerates to a single unit tap."""
+    xmin, xn, kk = IO.pil_bilinear_coeffs(8, 4)
+    one = 1 << IO.PRECISION_BITS
+    assert kk.shape[1] == 5 and list(xmin) == [0, 1, 3, 5] and list(xn) == [3, 4, 4, 3]
+    assert list(kk[1, :4]) == [one // 8, 3 * one // 8, 3 * one // 8, one // 8]
+    assert abs(int(kk[0].sum()) - one) <= 2 and abs(int(kk[3].sum()) - one) <= 2
+    xmin, xn, kk = IO.pil_bilinear_coeffs(5, 5)
+    assert all(int(kk[i, : xn[i]].max()) == one and int(kk[i].sum()) == one for i in range(5))
