@@ -156,6 +156,20 @@ def main(argv=None):
     ap.add_argument("--no-overlap", action="store_true", help="no RCCL/backward overlap")
     ap.add_argument("--serial", action="store_true", help="single-stream execution (no text-encoder / weight-gradient side streams)")
     args = ap.parse_args(argv)
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when its communicator initialises (seen on
+    # the MI355X box), so file descriptor 1 is pointed at stderr for the whole run and the line is written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return _run(args, real_stdout)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+
+
+def _run(args, real_stdout):
     conf = CONFIGS[args.config]
     batch = args.batch or conf["batch"]
 
@@ -333,7 +347,7 @@ def main(argv=None):
                           "backend": (args.backend if use_dist else None), "reducer": ("forced" if args.force_reducer and world == 1 else ("on" if world > 1 else "off")),
                           "bytes_allreduced_per_step": trainer.reducer.bytes_reduced // max(1, args.steps + args.warmup + 2) if trainer.reducer.active else 0},
                "final_loss": round(loss, 4), "roofline": roof, "cpu_baseline": cpu, "extras": extras}
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
     return out

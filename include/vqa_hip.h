@@ -28,16 +28,12 @@ typedef struct ihipStream_t* hipStream_t;
  * transposed = 1 gathers for the data gradient (a = dY [B,H,W,C], rows index dX [B,Ho,Wo]). */
 int vqa_igemm_mtiles(int M, int N, int loader);
 /* which template instantiation vqa_igemm launches for this problem (host-only query, no launch):
- * BM*10000 + BN*10 + flavour (0 plain LDS-DMA double buffer, 1 window loader, 2/3 8-wave 256x128 ring, 4/5 BK=32 shapes) */
+ * BM*10000 + BN*10 + flavour (0 plain LDS-DMA double buffer, 1 window loader) */
 int vqa_igemm_variant(int dtype, int loader, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
                       int R, int S, int stride, int pad);
 int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, const float* bias, const void* addend,
               const void* addmask, const void* outmask /* out *= (outmask > 0), applied last */, float* stats, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
-              /* fused BatchNorm-backward reduction of a data-gradient launch (bn_slab != NULL): the stored values are the gradient g
-                 entering the BatchNorm whose conv output is bn_y (bn_self: g *= [bn_y*scale+shift > 0]); per M tile
-                 sum g | sum g*xhat(bn_y) | sum g*xhat(bn_y2) -> bn_slab[vqa_igemm_mtiles][3][N], the layout vqa_bn_bwd_finalize reads */
-              const void* bn_y, const float* bn_coef, const void* bn_y2, const float* bn_coef2, float* bn_slab, int bn_self,
               hipStream_t stream);
 /* dw[N][Kw] += dy[M][N]^T * gather(x)[M][Kw], split over the M pixels.
  * With a workspace (`ws`, caller-owned scratch of >= the ws_floats vqa_wgrad_plan reports; contents undefined afterwards) every

@@ -94,27 +94,35 @@ def test_plain_128_tiles_linear_at_benchmark_rows():
         assert _relerr(out.float().cpu(), torch.relu(x @ w.t() + b)) < 1.2e-2
 
 
-WGRAD = [  # B, Cin, Cout, H, R, stride, pad, note
-    (128, 128, 128, 28, 3, 1, 1, "stage 2: 128x128 tile, inputs >= 80x dW -> XCD-aware workgroup order"),
-    (64, 64, 128, 56, 3, 2, 1, "stage-2 entry conv 3x3/2: 128x64 tile, XCD-aware order"),
-    (64, 64, 128, 56, 1, 2, 0, "stage-2 shortcut 1x1/2: 128x64 tile"),
-    (128, 256, 256, 14, 3, 1, 1, "stage 3: 128x128 tile, plain order"),
-    (256, 512, 512, 7, 3, 1, 1, "stage 4: 128x128 tile, plain order, 144 output tiles"),
-    (128, 128, 256, 28, 3, 2, 1, "stage-3 entry conv 3x3/2"),
+WGRAD = [  # B, Cin, Cout, H, R, stride, pad, (kind, tile_n, tile_k) the B=512 benchmark launch of this layer gets, note
+    (128, 128, 128, 28, 3, 1, 1, (0, 128, 128), "stage 2 (vqa_wgrad route; the engine uses wgrad3x3_c128p): 4-wave 128x128, XCD-aware order"),
+    (272, 64, 128, 56, 3, 2, 1, (1, 128, 256), "stage-2 entry conv 3x3/2: 8-wave LDS-DMA kernel, 128x256 tile"),
+    (64, 64, 128, 56, 1, 2, 0, (0, 128, 64), "stage-2 shortcut 1x1/2: 4-wave 128x64 tile"),
+    (160, 256, 256, 14, 3, 1, 1, (1, 256, 256), "stage 3: 8-wave LDS-DMA kernel, 256x256 tile"),
+    (256, 512, 512, 7, 3, 1, 1, (1, 256, 256), "stage 4: 8-wave LDS-DMA kernel, 256x256 tile, 144 output tiles"),
+    (272, 128, 256, 28, 3, 2, 1, (1, 256, 256), "stage-3 entry conv 3x3/2: 8-wave LDS-DMA kernel"),
+    (128, 128, 256, 28, 1, 2, 0, (0, 128, 128), "stage-3 shortcut 1x1/2: 4-wave 128x128 tile"),
 ]
 
 
-@pytest.mark.parametrize("case", WGRAD)
+@pytest.mark.parametrize("case", WGRAD, ids=[c[-1].split(":")[0] for c in WGRAD])
 def test_wgrad_at_benchmark_tiles(case):
+    """Every case first asserts -- through vqa_wgrad_plan, the host function the launch itself uses -- that the test shape gets the
+    SAME kernel kind and tile as the B=512 benchmark launch of that layer (the planner switches kernels on the problem's FLOPs, so
+    a small batch would silently test a different kernel), then compares with ATen on bf16-rounded operands."""
     K = sub("kernels")
-    B, Cin, Cout, H, R, stride, pad, _ = case
+    B, Cin, Cout, H, R, stride, pad, expect, _ = case
     g = torch.Generator().manual_seed(Cin * 3 + H + R)
     Ho = (H + 2 * pad - R) // stride + 1
+    M, Kw = B * Ho * Ho, R * R * Cin
+    plan = K.wgrad_plan(BF, 0, M, Cout, Kw, B, H, H, Cin, R, R)
+    bench = K.wgrad_plan(BF, 0, 512 * Ho * Ho, Cout, Kw, 512, H, H, Cin, R, R)
+    assert plan[:3] == expect and bench[:3] == expect, (plan, bench, expect)
+    assert plan[3] > 1 and plan[4] == plan[3] * Cout * Kw            # split over M with one slab per split: the fixed-order two-pass path
     x = _round(torch.randn(B, Cin, H, H, generator=g))
     dy = _round(torch.randn(B, Cout, Ho, Ho, generator=g))
     w = torch.zeros(Cout, Cin, R, R, requires_grad=True)
     F.conv2d(x, w, None, stride=stride, padding=pad).backward(dy)
-    M, Kw = B * Ho * Ho, R * R * Cin
     geom = (B, H, H, Cin, Ho, Ho, R, R, stride, pad)
     dw = torch.zeros(Cout, Kw, device=DEV)
     K.wgrad(_nhwc(dy).to(DEV, BF), _nhwc(x).to(DEV, BF), dw, M, Cout, Kw, geom, dtype=BF)
@@ -167,49 +175,6 @@ def test_weight_gradients_are_bit_reproducible():
     K.wgrad(dy, x, b, M, N, Kin, K.linear_geom(M, Kin), dtype=BF)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
-
-
-@pytest.mark.parametrize("case", [(16, 64, 56, True, False), (64, 128, 28, False, True), (4, 128, 12, False, False), (3, 64, 10, True, False)])
-@pytest.mark.parametrize("dtype", [BF, torch.float32])
-def test_data_gradient_epilogue_reduces_batchnorm_backward_sums(case, dtype):
-    """igemm(transposed, bnred=...): the data-gradient launch also emits the BatchNorm-backward column sums of the gradient it
-    stores -- sum g, sum g*xhat(y) [, sum g*xhat(y2)] with g = stored value (* [y*scale+shift > 0] in self-mask mode), after the
-    identity addend and the hand-over mask -- per M tile, in the slab layout vqa_bn_bwd_finalize reads.  Checked against torch on
-    the values the kernel actually stored (so only fp32 summation order differs), at the benchmark tiles (window loader, 128x64 and
-    128x128) and at the 64x64 fallback."""
-    K = sub("kernels")
-    B, C, H, self_mask, dual = case
-    if dtype == torch.float32 and B * H * H > 20000:
-        pytest.skip("fp32 path: small shapes only (exact-fp32 MFMA is 16x slower)")
-    g = torch.Generator().manual_seed(C + H + int(self_mask))
-    rnd = lambda *s: torch.randn(*s, generator=g).to(dtype)
-    M, Kw = B * H * H, 9 * C
-    dy, y, y2, add, om = rnd(M, C), rnd(M, C), rnd(M, C), rnd(M, C), rnd(M, C)
-    w = (torch.randn(C, 9, C, generator=g) * (2.0 / Kw) ** 0.5)
-    coef = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.2,
-                        torch.rand(C, generator=g) + 0.5])                      # scale | shift | mean | invstd
-    coef2 = torch.stack([torch.ones(C), torch.zeros(C), torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5])
-    geom = (B, H, H, C, H, H, 3, 3, 1, 1)
-    wt = K.pack_transpose(w.to(DEV), dtype)
-    bnred = (y.to(DEV), coef.to(DEV), self_mask) + ((y2.to(DEV), coef2.to(DEV)) if dual else ())
-    kw = {} if self_mask else dict(addend=add.to(DEV), outmask=om.to(DEV))
-    dx, slab, mt = K.igemm(dy.to(DEV), wt, M, C, Kw, geom, dtype=dtype, transposed=1, bnred=bnred, **kw)
-    plain, _, _ = K.igemm(dy.to(DEV), wt, M, C, Kw, geom, dtype=dtype, transposed=1, **kw)
-    torch.cuda.synchronize()
-    assert torch.equal(dx, plain)                                           # the fused reduction does not change the stored gradient
-    assert slab.shape == (mt, 3, C)
-    gq = dx.float().cpu()
-    yf = y.float()
-    if self_mask:
-        gq = gq * ((yf * coef[0] + coef[1]) > 0)
-    ref0 = gq.sum(0)
-    ref1 = (gq * (yf - coef[2]) * coef[3]).sum(0)
-    s = slab.sum(0).cpu()
-    tol = lambda r: 2e-3 * float(r.abs().max()) + 1e-3
-    assert (s[0] - ref0).abs().max().item() < tol(ref0) and (s[1] - ref1).abs().max().item() < tol(ref1)
-    if dual:
-        ref2 = (gq * (y2.float() - coef2[2]) * coef2[3]).sum(0)
-        assert (s[2] - ref2).abs().max().item() < tol(ref2)
 
 
 def test_grouped_linear_weight_gradients_equal_single_launches():

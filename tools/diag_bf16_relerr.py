@@ -1,0 +1,37 @@
+"""Relative L2 error per parameter tensor of the HIP bf16 gradients against the fp32 CPU oracle at batch B (default 64): the input
+for the bounds of tests/test_gpu_model.py::test_train_bf16_gradients_at_batch64.  Usage: python tools/diag_bf16_relerr.py [B] [dtype]"""
+import importlib, os, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle import vqa_oracle as O
+pkg = importlib.import_module("visual-question-answering-vqa-system_amd")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+torch.set_num_threads(16)
+cfg = O.full_config(dropout=0.0, answer_dropout=0.0)
+sd = O.init_state_dict(cfg, 7, jitter=True)
+images, ids, mask, answers = O.synthetic_batch(B, seed=77)
+names = O.parameter_names(cfg)
+tr = O.OracleTrainer(sd, cfg)
+lo, _ = O.vqa_forward(images, ids, mask, tr.sd, cfg, True, {})
+loss = torch.nn.functional.cross_entropy(lo, answers)
+loss.backward()
+ref = {n: tr.sd[n].grad.float().reshape(-1) for n in names}
+m = pkg.load_dropin().VQAModel(**cfg, compute_dtype=dtype)
+m.load_state_dict(sd)
+m = m.to("cuda").train()
+logits, _ = m(images.cuda(), ids.cuda(), mask.cuda())
+l2 = torch.nn.functional.cross_entropy(logits, answers.cuda())
+l2.backward()
+P = dict(m.named_parameters())
+rows = []
+for n in names:
+    g = P[n].grad.detach().float().cpu().reshape(-1)
+    rn = float(ref[n].norm())
+    rows.append((float((g - ref[n]).norm()) / max(rn, 1e-30), n, rn, P[n].dim()))
+print(f"B={B} {dtype} loss ref {float(loss):.5f} hip {float(l2):.5f} logits maxdiff {float((logits.cpu() - lo).abs().max()):.4f}")
+for e, n, rn, d in sorted(rows, reverse=True)[:40]:
+    print(f"{e:8.4f}  dim{d}  |g|={rn:9.3e}  {n}")
+G = torch.cat([P[n].grad.detach().float().cpu().reshape(-1) for n in names]); R = torch.cat([ref[n] for n in names])
+print("whole-model relerr", float((G - R).norm() / R.norm()), " max over >=2-D:", max(e for e, n, rn, d in rows if d >= 2), " max over 1-D:", max(e for e, n, rn, d in rows if d < 2))

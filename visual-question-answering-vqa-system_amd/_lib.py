@@ -19,7 +19,7 @@ P, I, F, D, LL, ULL = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong, 
 SIGNATURES = {
     "vqa_igemm_mtiles": [I, I, I],
     "vqa_igemm_variant": [I] * 15,
-    "vqa_igemm": [I, I, P, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, P, P, P, P, P, I, P],
+    "vqa_igemm": [I, I, P, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, P],
     "vqa_wgrad_plan": [I] * 11 + [P, P, P, P, P],
     "vqa_wgrad": [I, I, P, P, P] + [I] * 13 + [P, LL, P],
     "vqa_pack_rows": [I, P, P, I, I, I, P],

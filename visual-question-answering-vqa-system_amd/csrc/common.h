@@ -3,6 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
+// Measurement / ablation switches (tile choices, and the VQA_*_DBG phase switches that give WRONG results on purpose) are
+// environment variables only in builds made with -DVQA_ABLATION (tools/build_ablation.py makes its own libvqa_hip_ablation.so).
+// The product library ignores the environment: every switch is its shipped default, folded at compile time.
+#ifdef VQA_ABLATION
+static inline int vqa_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline int vqa_env_int(const char*, int dflt) { return dflt; }
+#endif
+
 #define VQA_OK 0
 #define VQA_EARG 1000   // argument / shape error (never launches)
 

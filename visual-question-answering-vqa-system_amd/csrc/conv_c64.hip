@@ -905,7 +905,7 @@ int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int 
   C64Params p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats; p.addend = nullptr; p.addmask = nullptr;
   p.B = B; p.H = H; p.W = W;
-  static const int dbg_env = getenv("VQA_C64P_DBG") ? atoi(getenv("VQA_C64P_DBG")) : 0;
+  const int dbg_env = vqa_env_int("VQA_C64P_DBG", 0);
   p.dbg = dbg_env;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
@@ -920,7 +920,7 @@ int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int 
 // accumulation (NULL or too small: fp32 atomics)
 // Stage-2 shape only (3x3 / 1 / pad 1, 128 -> 128 channels, 28 x 28 maps, bf16): slabs needed (= workgroups) or 0 when unsupported
 int vqa_wgrad3x3_c128_blocks(int B, int H, int W) {
-  static const int en = getenv("VQA_C128WP") ? atoi(getenv("VQA_C128WP")) : 1;
+  const int en = vqa_env_int("VQA_C128WP", 1);
   if (!en || H != C128_W || W != C128_W || B <= 0 || (size_t)B * H * W * 128 * 2 >= 0x7fffffffull) return 0;
   const int nblocks = B * (C128_W / C128_RB);
   int per_half = nblocks < 128 ? nblocks : 128;
@@ -946,14 +946,14 @@ int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int
   if (!x || !dy || !dw || grid <= 0) return VQA_EARG;
   C64WgradParams p;
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.B = B; p.H = H; p.W = W;
-  static const int dbg_env = getenv("VQA_C64WP_DBG") ? atoi(getenv("VQA_C64WP_DBG")) : 0;
+  const int dbg_env = vqa_env_int("VQA_C64WP_DBG", 0);
   p.dbg = dbg_env;
   p.ws = (ws && ws_floats >= (long long)grid * 64 * 576) ? ws : nullptr;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)xb;
   // 8-wave LDS-DMA form (needs the slab workspace: it has no atomic flush); VQA_C64WP=0 keeps the 4-wave kernel (measurement)
-  static const int wp_env = getenv("VQA_C64WP") ? atoi(getenv("VQA_C64WP")) : 1;
+  const int wp_env = vqa_env_int("VQA_C64WP", 1);
   const size_t shm_p = (size_t)2 * ((size_t)(RBW + 2) * (W + 2) * 128 + (size_t)((RBW * W + 31) / 32 * 32) * 128);
   const int nblk_p = B * (H / RBW), grid_p = nblk_p < 256 ? nblk_p : 256;
   if (wp_env && p.ws && H % RBW == 0 && W % 8 == 0 && shm_p <= 160 * 1024 && grid_p <= grid) {

@@ -20,11 +20,6 @@ struct IGemmParams {
   const void* a; const void* w; void* out;
   const float* bias; const void* addend; const void* addmask; float* stats;
   const void* outmask;       // != nullptr: out = (... + addend) * (outmask > 0): the consumer's ReLU mask applied by the producer
-  // BatchNorm-backward reduction fused into a data-gradient epilogue (bn_slab != nullptr): the tile's final values ARE the
-  // gradient g (bn_self: times [bn_y*scale + shift > 0], the ReLU recomputed from the conv output) entering the BatchNorm whose
-  // conv output is bn_y; per M tile the column sums  sum g | sum g*xhat(bn_y) | sum g*xhat(bn_y2)  go to bn_slab[tile][3][N]
-  // (the layout vqa_bn_bwd_finalize reads), so the standalone reduce pass over g and y is not run.
-  const void* bn_y; const float* bn_coef; const void* bn_y2; const float* bn_coef2; float* bn_slab; int bn_self;
   int M, N, Kp, Kw;          // Kp: reduction length rounded up to BK; Kw: weight row length (elements)
   int B, H, W, C;            // source tensor (NHWC; NCHW fp32 image for the stem loader)
   int Ho, Wo;                // spatial dims of the GEMM rows (M = B*Ho*Wo)
@@ -116,9 +111,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// BNRED: the epilogue also reduces BatchNorm-backward column sums (data-gradient launches); a separate instantiation so that the
-// forward / plain kernels keep the lean epilogue (its register arrays cost the 128x64 shape its third workgroup per CU).
-template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2, int WIN = 0, bool BNRED = false>
+template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2, int WIN = 0>
 __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   // OCC waves per SIMD (2 -> <= 256 VGPRs)
   using G = GT<T>;
   constexpr int VEC = G::VEC, LD = BK;
@@ -479,21 +472,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
 
   }
 
-  // BNRED: the BatchNorm operand rows this thread will need in the store loop are requested NOW, so their latency hides under the
-  // accumulator conversion / LDS staging below instead of serialising the store loop (the loop then issues no loads at all in the
-  // common self-mask case: conv2's data gradient).
-  constexpr int VR_ = BN / VEC, RP_ = NTHR / VR_, NR_ = BM / RP_;
-  Vec16<T> ypre[BNRED ? NR_ : 1];
-  if constexpr (BNRED) {
-    const T* byT = reinterpret_cast<const T*>(p.bn_y);
-    const int nn = n0 + (tid % VR_) * VEC;
-#pragma unroll
-    for (int i = 0; i < NR_; ++i) {
-      const int m = m0 + tid / VR_ + i * RP_;
-      ypre[i] = (m < row_limit && nn < p.N && (p.N % VEC) == 0) ? ldg16(byT + (size_t)m * p.N + nn) : zero16<T>();
-    }
-  }
-
   // ---- epilogue.  The MFMA operands were swapped, so a lane holds 4 CONSECUTIVE COLUMNS of one row:
   //        acc[i][j][r] = C[m = wm*TM + i*16 + (lane & 15)][n = wn*64 + j*16 + (lane >> 4)*4 + r]
   //      -> packed conversion and one 8-byte (bf16) / 16-byte (fp32) LDS store per (i, j) instead of four scalar ones.
@@ -612,23 +590,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
   const T* mskT = reinterpret_cast<const T*>(p.addmask);
   const T* omT = reinterpret_cast<const T*>(p.outmask);
   const bool vec_ok = (p.N % VEC) == 0;
-  // fused BatchNorm-backward reduction: this thread's VEC columns are the same for all its rows
-  const T* bnyT = reinterpret_cast<const T*>(p.bn_y);
-  const T* bny2T = reinterpret_cast<const T*>(p.bn_y2);
-  constexpr bool bnred = BNRED;
-  constexpr int BV_ = BNRED ? VEC : 1;
-  float bsg[BV_], bsx[BV_], bsx2[BV_], bmean[BV_], binv[BV_], bms[BV_], bmh[BV_], bmean2[BV_], binv2[BV_];
-  if constexpr (BNRED) {
-    const int nc = n0 + (tid % VR) * VEC;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const bool ok = nc + j < p.N;
-      bsg[j] = bsx[j] = bsx2[j] = 0.f;
-      bmean[j] = ok ? p.bn_coef[2 * p.N + nc + j] : 0.f; binv[j] = ok ? p.bn_coef[3 * p.N + nc + j] : 0.f;
-      bms[j] = (ok && p.bn_self) ? p.bn_coef[nc + j] : 0.f; bmh[j] = (ok && p.bn_self) ? p.bn_coef[p.N + nc + j] : 0.f;
-      bmean2[j] = (ok && bny2T) ? p.bn_coef2[2 * p.N + nc + j] : 0.f; binv2[j] = (ok && bny2T) ? p.bn_coef2[3 * p.N + nc + j] : 0.f;
-    }
-  }
   // The thread's rows are handled in chunks of CHR: ALL global loads of a chunk (addend, masks, BatchNorm operand) are issued
   // before its first store -- a load behind a store to a possibly aliasing pointer waits for it, and eight dependent
   // load -> store round trips per tile were a third of the data-gradient launches' time.
@@ -637,7 +598,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
   const int n = n0 + (tid % VR) * VEC;
   for (int r0 = 0; r0 < NR; r0 += CHR) {
     size_t offs[CHR]; bool live[CHR];
-    Vec16<T> av[CHR], mv[CHR], ov[CHR], y2v[BNRED ? CHR : 1];
+    Vec16<T> av[CHR], mv[CHR], ov[CHR];
 #pragma unroll
     for (int i = 0; i < CHR; ++i) {
       const int row = tid / VR + (r0 + i) * RP;
@@ -652,7 +613,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
         if (addT) av[i] = ldg16(addT + offs[i]);
         if (addT && mskT) mv[i] = ldg16(mskT + offs[i]);
         if (omT) ov[i] = ldg16(omT + offs[i]);
-        if constexpr (BNRED) { if (bny2T) y2v[i] = ldg16(bny2T + offs[i]); }
       }
     }
 #pragma unroll
@@ -680,17 +640,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
           for (int j = 0; j < VEC; ++j) if (!(ov[i].get(j) > 0.f)) v.set(j, 0.f);
         }
         stg16(outT + off, v);
-        if constexpr (BNRED) {                         // sums over the values exactly as stored (v is already rounded to T)
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            float gq = v.get(j);
-            const float yy = ypre[r0 + i].get(j);
-            if (p.bn_self && !(yy * bms[j] + bmh[j] > 0.f)) gq = 0.f;
-            bsg[j] += gq;
-            bsx[j] += gq * (yy - bmean[j]) * binv[j];
-            if (bny2T) bsx2[j] += gq * (y2v[i].get(j) - bmean2[j]) * binv2[j];
-          }
-        }
       } else {
         for (int j = 0; j < VEC && n + j < p.N; ++j) {
           float x = v.get(j);
@@ -699,36 +648,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
           if (omT && !(to_f<T>(omT[off + j]) > 0.f)) x = 0.f;
           outT[off + j] = from_f<T>(x);
         }
-      }
-    }
-  }
-  if constexpr (BNRED) {
-    // lanes VR apart hold the same columns: fold them inside the wave, then the NW waves through LDS, in a fixed order
-#pragma unroll
-    for (int j = 0; j < VEC; ++j)
-#pragma unroll
-      for (int o = VR; o < 64; o <<= 1) {
-        bsg[j] += __shfl_xor(bsg[j], o, 64); bsx[j] += __shfl_xor(bsx[j], o, 64); bsx2[j] += __shfl_xor(bsx2[j], o, 64);
-      }
-    float* red2 = reinterpret_cast<float*>(smem + IGemmCfg<T, BM, BN, BK, ST, WIN>::CST);     // [NW][3][BN] floats
-    static_assert(NW * 3 * BN * 4 <= IGemmCfg<T, BM, BN, BK, ST, WIN>::SMEM - IGemmCfg<T, BM, BN, BK, ST, WIN>::CST, "bn scratch");
-    __syncthreads();                                   // the statistics scratch / C staging reads are done
-    {
-      if (lane < VR) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          red2[(wave * 3 + 0) * BN + lane * VEC + j] = bsg[j];
-          red2[(wave * 3 + 1) * BN + lane * VEC + j] = bsx[j];
-          red2[(wave * 3 + 2) * BN + lane * VEC + j] = bsx2[j];
-        }
-      }
-      __syncthreads();
-      for (int o = tid; o < 3 * BN; o += NTHR) {
-        const int k = o / BN, c = o - k * BN;
-        float a = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) a += red2[(w * 3 + k) * BN + c];
-        if (n0 + c < p.N) p.bn_slab[((size_t)tile_m * 3 + k) * p.N + n0 + c] = a;
       }
     }
   }
@@ -1390,56 +1309,41 @@ __global__ void fold_bn_batch_kernel(const float* __restrict__ flat, T* __restri
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2, int WIN = 0, bool BNRED = false>
+// (the static attr_set flags below are per PROCESS: one process drives one GPU -- the launch model of this library, bench.py and
+// torch.distributed; a process that drove several devices would have to set the attribute per device)
+template <typename T, int BM, int BN, int LOADER, int NW = 4, int BK = GT<T>::BK, int OCC = 2, int ST = 2, int WIN = 0>
 static int launch_igemm(const IGemmParams& p, hipStream_t st) {
   constexpr int SMEM = IGemmCfg<T, BM, BN, BK, ST, WIN>::SMEM;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST, WIN, BNRED>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST, WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST, WIN, BNRED>), dim3(tiles), dim3(NW * 64), SMEM, st, p);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, LOADER, NW, BK, OCC, ST, WIN>), dim3(tiles), dim3(NW * 64), SMEM, st, p);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }
 
 static void igemm_tile(int M, int N, int* bm, int* bn) {
-  static int bm_env = -1;
-  if (bm_env < 0) { const char* e = getenv("VQA_IGEMM_BM"); bm_env = e ? atoi(e) : 128; }
-  static int bm64_env = -1;
-  if (bm64_env < 0) { const char* e = getenv("VQA_IGEMM_BM64"); bm64_env = e ? atoi(e) : 128; }
-  if (N <= 64) { *bn = 64; *bm = (bm64_env == 256 && M >= 256 * 256) ? 256 : 128; }      // (256-row tiles were measured slower for the 64-channel layers)
-  else { *bn = 128; *bm = (bm_env >= 256 && M >= 256 * 256) ? 256 : 128; }   // 256 / 257: opt-in 8-wave 256x128 tile (2 / 3 slots)
+  *bm = 128; *bn = N <= 64 ? 64 : 128;
   long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
   if (tiles < 384) { *bm = 64; *bn = 64; }
 }
 
 // The ONE place that picks the template instantiation of a launch; vqa_igemm_variant() reports it to the host (parity tests assert
 // that the shapes they run reach the kernels the benchmark times).  code = BM*10000 + BN*10 + flavour:
-//   0 plain double-buffered LDS-DMA, 1 window loader (stride-1 3x3 pad-1, bf16), 2 8-wave 256x128 ring-2, 3 ring-3, 4 / 5 BK=32 shapes
+//   0 plain double-buffered LDS-DMA, 1 window loader (stride-1 3x3 pad-1, bf16).
+// (Rounds 1-2 also built 8-wave 256x128 / 256x64 tiles, a 3-slot ring, two BK = 32 shapes and an epilogue that reduced the
+// BatchNorm-backward sums; all measured slower on MI355X -- DESIGN.md section 3 -- and were deleted in round 3.)
 static int igemm_variant(const IGemmParams& p, int loader, bool bf16) {
   int bm, bn; igemm_tile(p.M, p.N, &bm, &bn);
   if (loader == LOADER_STEM) return 128 * 10000 + 64 * 10;
   if (bf16) {
-    static const int win_env = getenv("VQA_IGEMM_WIN") ? atoi(getenv("VQA_IGEMM_WIN")) : 1;
-    if (win_env && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.H == p.Ho && p.W == p.Wo && p.C % 64 == 0 && bm == 128 &&
+    const int win = vqa_env_int("VQA_IGEMM_WIN", 1);
+    if (win && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.H == p.Ho && p.W == p.Wo && p.C % 64 == 0 && bm == 128 &&
         (long)p.B * p.H * p.W == (long)p.M)
       return 128 * 10000 + bn * 10 + 1;
-    if (win_env && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.H == p.Ho && p.W == p.Wo && p.C % 64 == 0 && bm == 256 && bn == 64 &&
-        (long)p.B * p.H * p.W == (long)p.M)
-      return 256 * 10000 + 64 * 10 + 1;
-  }
-  if (bm == 256 && bn == 128) {
-    if (!bf16) return 128 * 10000 + 128 * 10;
-    static const int ring3 = getenv("VQA_IGEMM_BM") && atoi(getenv("VQA_IGEMM_BM")) == 257;
-    return 256 * 10000 + 128 * 10 + (ring3 ? 3 : 2);
-  }
-  if (bm == 128 && bn == 128 && bf16) {
-    // 2 waves x (128 x 64), BK = 32: needs whole 64-wide K steps (the host rounds Kp to 64) -> any conv / Linear without a K tail
-    static int w2 = -1;
-    if (w2 < 0) { const char* e = getenv("VQA_IGEMM_W2"); w2 = e ? atoi(e) : 0; }
-    if ((w2 == 1 || w2 == 2) && p.Kw % 64 == 0) return 128 * 10000 + 128 * 10 + 3 + w2;
   }
   return bm * 10000 + bn * 10;
 }
@@ -1448,27 +1352,10 @@ template <typename T>
 static int igemm_dispatch(const IGemmParams& p, int loader, hipStream_t st) {
   const int v = igemm_variant(p, loader, sizeof(T) == 2);
   if (loader == LOADER_STEM) return launch_igemm<T, 128, 64, LOADER_STEM>(p, st);
-  if (p.bn_slab) {                                 // data gradient + fused BatchNorm-backward reduction
-    if constexpr (sizeof(T) == 2) {
-      if (v == 128 * 10000 + 128 * 10 + 1) return launch_igemm<T, 128, 128, LOADER_NHWC, 4, 64, 2, 2, 1, true>(p, st);
-      if (v == 128 * 10000 + 64 * 10 + 1) return launch_igemm<T, 128, 64, LOADER_NHWC, 4, 64, 2, 2, 1, true>(p, st);
-    }
-    switch (v) {
-      case 128 * 10000 + 128 * 10: return launch_igemm<T, 128, 128, LOADER_NHWC, 4, GT<T>::BK, 2, 2, 0, true>(p, st);
-      case 128 * 10000 + 64 * 10: return launch_igemm<T, 128, 64, LOADER_NHWC, 4, GT<T>::BK, 2, 2, 0, true>(p, st);
-      case 64 * 10000 + 64 * 10: return launch_igemm<T, 64, 64, LOADER_NHWC, 4, GT<T>::BK, 2, 2, 0, true>(p, st);
-      default: return VQA_EARG;                    // (opt-in measurement shapes have no fused-reduction build)
-    }
-  }
   if constexpr (sizeof(T) == 2) {
     switch (v) {
       case 128 * 10000 + 128 * 10 + 1: return launch_igemm<T, 128, 128, LOADER_NHWC, 4, 64, 2, 2, 1>(p, st);
       case 128 * 10000 + 64 * 10 + 1: return launch_igemm<T, 128, 64, LOADER_NHWC, 4, 64, 2, 2, 1>(p, st);
-      case 256 * 10000 + 64 * 10 + 1: return launch_igemm<T, 256, 64, LOADER_NHWC, 8, 64, 2, 2, 1>(p, st);
-      case 256 * 10000 + 128 * 10 + 2: return launch_igemm<T, 256, 128, LOADER_NHWC, 8, 64, 2, 2>(p, st);
-      case 256 * 10000 + 128 * 10 + 3: return launch_igemm<T, 256, 128, LOADER_NHWC, 8, 64, 2, 3>(p, st);
-      case 128 * 10000 + 128 * 10 + 4: return launch_igemm<T, 128, 128, LOADER_NHWC, 2, 32>(p, st);
-      case 128 * 10000 + 128 * 10 + 5: return launch_igemm<T, 128, 128, LOADER_NHWC, 4, 32, 3>(p, st);
       default: break;
     }
   }
@@ -1544,9 +1431,9 @@ struct WgradPlan { int kind, tn, tk, nsplit, chunk, xcd_order; long long ws_floa
 static WgradPlan wgrad_plan(int dtype, int loader, int M, int N, int Kw, int B, int H, int W, int C, int R, int S, bool have_ws) {
   WgradPlan pl = {0, 64, 64, 1, 0, 1, 0};
   const bool conv = R * S > 1;
-  static const int dma_env = getenv("VQA_WGRAD_DMA") ? atoi(getenv("VQA_WGRAD_DMA")) : 1;     // measurement: 0 never, 2 whenever eligible
-  static const long target_env = getenv("VQA_WGRAD_TARGET") ? atol(getenv("VQA_WGRAD_TARGET")) : 0;
-  static const long minrows_env = getenv("VQA_WGRAD_MINCHUNK") ? atol(getenv("VQA_WGRAD_MINCHUNK")) : 0;
+  const int dma_env = vqa_env_int("VQA_WGRAD_DMA", 1);     // measurement (-DVQA_ABLATION builds only): 0 never, 2 whenever eligible
+  const long target_env = vqa_env_int("VQA_WGRAD_TARGET", 0);
+  const long minrows_env = vqa_env_int("VQA_WGRAD_MINCHUNK", 0);
   const double flops = 2.0 * M * N * Kw;
   bool dma = have_ws && dma_env && dtype && loader == LOADER_NHWC && N >= 128 && (N % 8) == 0 && Kw >= 64 && (Kw % 64) == 0 &&
              (C % 64) == 0 && M >= 256 && (conv || C == Kw);
@@ -1554,7 +1441,7 @@ static WgradPlan wgrad_plan(int dtype, int loader, int M, int N, int Kw, int B, 
   if (dma) {
     // tile: least padded work, the 256x256 tile (128x64 wave tiles) preferred
     static const int cand[3][2] = {{256, 256}, {128, 256}, {256, 128}};
-    static const int force = getenv("VQA_WGRAD_TILE") ? atoi(getenv("VQA_WGRAD_TILE")) : -1;     // measurement: 0 / 1 / 2 forces a candidate
+    const int force = vqa_env_int("VQA_WGRAD_TILE", -1);     // measurement: 0 / 1 / 2 forces a candidate
     double best = 1e300;
     for (int c = 0; c < 3; ++c) {
       if (force >= 0 && force != c) continue;
@@ -1613,8 +1500,7 @@ int vqa_igemm_mtiles(int M, int N, int loader) {
   return (M + bm - 1) / bm;
 }
 
-// Template instantiation vqa_igemm picks for this problem: BM*10000 + BN*10 + flavour (0 plain, 1 window loader, 2/3 256x128
-// 8-wave ring, 4/5 BK=32 shapes).  Pure host function, no launch.
+// Template instantiation vqa_igemm picks for this problem: BM*10000 + BN*10 + flavour (0 plain, 1 window loader).  Pure host function.
 int vqa_igemm_variant(int dtype, int loader, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad) {
   IGemmParams p;
   p.M = M; p.N = N; p.Kw = Kw; p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
@@ -1625,10 +1511,8 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
               const void* addend, const void* addmask, const void* outmask, float* stats,
               int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
-              const void* bn_y, const float* bn_coef, const void* bn_y2, const float* bn_coef2, float* bn_slab, int bn_self,
               hipStream_t st) {
   if (M <= 0 || N <= 0 || !a || !w || !out) return VQA_EARG;
-  if (bn_slab && (!bn_y || !bn_coef || (bn_y2 && !bn_coef2) || (N % (dtype ? 8 : 4)) || loader != LOADER_NHWC)) return VQA_EARG;
   const int VEC = dtype ? 8 : 4, BK = dtype ? 64 : 32;
   if (loader == LOADER_NHWC) {
     if (C % VEC) return VQA_EARG;
@@ -1644,7 +1528,6 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
   p.M = M; p.N = N; p.Kw = Kw; p.Kp = (Kw + BK - 1) / BK * BK;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
   p.transposed = transposed; p.relu = relu; p.drop_p = drop_p; p.drop_seed = drop_seed; p.a2 = nullptr;
-  p.bn_y = bn_y; p.bn_coef = bn_coef; p.bn_y2 = bn_y2; p.bn_coef2 = bn_coef2; p.bn_slab = bn_slab; p.bn_self = bn_self;
   {
     const size_t es = dtype ? 2 : 4;
     const size_t ab = (size_t)B * H * W * C * es, wb = (size_t)N * Kw * es;
@@ -1659,8 +1542,7 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
     p.mul_wo = (one + (unsigned long long)Wo - 1) / (unsigned long long)Wo;
   }
   for (int c = 0; c < 4; ++c) p.ntaps[c] = 0;
-  static const int dbg_env = getenv("VQA_IGEMM_DBG") ? atoi(getenv("VQA_IGEMM_DBG")) : 0;
-  p.dbg = dbg_env;
+  p.dbg = vqa_env_int("VQA_IGEMM_DBG", 0);       // ablation switches (wrong results): compiled out unless -DVQA_ABLATION
   return dtype ? igemm_dispatch<bf16_t>(p, loader, st) : igemm_dispatch<float>(p, loader, st);
 }
 
@@ -1673,7 +1555,6 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
   if (!dy || !wt || !out || (Ho & 1) || (Wo & 1) || C % BK || N % VEC || R > 3 || R < 1) return VQA_EARG;
   IGemmParams p;
   p.a = dy; p.a2 = dyd; p.w = wt; p.out = out; p.bias = nullptr; p.addend = nullptr; p.addmask = nullptr; p.stats = nullptr; p.outmask = nullptr;
-  p.bn_y = nullptr; p.bn_coef = nullptr; p.bn_y2 = nullptr; p.bn_coef2 = nullptr; p.bn_slab = nullptr; p.bn_self = 0;
   p.N = N; p.Kw = R * R * C + (dyd ? C : 0); p.Kp = p.Kw; p.M = B * Ho * Wo;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = R; p.stride = 2; p.pad = pad;
   p.transposed = 1; p.relu = 0; p.drop_p = 0.f; p.drop_seed = 0;
@@ -1763,14 +1644,14 @@ int vqa_wgrad(int dtype, int loader, const void* dy, const void* x, float* dw,
   p.ws = pl.ws_floats > 0 ? ws : nullptr;
   p.chunk = pl.chunk;
   if (pl.kind == 1) {
-    static const int dbg_env = getenv("VQA_WGRAD_DBG") ? atoi(getenv("VQA_WGRAD_DBG")) : 0;
+    const int dbg_env = vqa_env_int("VQA_WGRAD_DBG", 0);
     p.dbg_noatomic = dbg_env;
     if (pl.tn == 256 && pl.tk == 256) return launch_wgrad_dma<256, 256, 2>(p, pl.nsplit, st);
     if (pl.tn == 128 && pl.tk == 256) return launch_wgrad_dma<128, 256, 2>(p, pl.nsplit, st);
     return launch_wgrad_dma<256, 128, 2>(p, pl.nsplit, st);
   }
   if (loader == LOADER_NHWC && R * S > 1 && (C % pl.tk)) return VQA_EARG;
-  static const int nostage = getenv("VQA_WGRAD_NOSTAGE") ? atoi(getenv("VQA_WGRAD_NOSTAGE")) : 0;
+  const int nostage = vqa_env_int("VQA_WGRAD_NOSTAGE", 0);
   p.dbg_noatomic = nostage;      // A/B switches: bit 0 = atomic flush straight from the accumulators, bit 1 = plain (not XCD-aware) workgroup order
   if (!pl.xcd_order) p.dbg_noatomic |= 2;
   int rc;
@@ -1803,7 +1684,7 @@ long long vqa_wgrad_group_ws(int dtype, int njobs, const int* M, const int* N, c
 int vqa_wgrad_group(int dtype, int njobs, const void* const* dy, const void* const* x, float* const* dw, const int* M, const int* N,
                     const int* Kw, float* ws, long long ws_floats, hipStream_t st) {
   if (njobs <= 0 || njobs > WG_MAXJOBS || !dy || !x || !dw || !M || !N || !Kw) return VQA_EARG;
-  static const int nostage = getenv("VQA_WGRAD_NOSTAGE") ? atoi(getenv("VQA_WGRAD_NOSTAGE")) : 0;
+  const int nostage = vqa_env_int("VQA_WGRAD_NOSTAGE", 0);
   WgradGroup g; ReduceGroup r;
   g.n = r.n = njobs; g.blk0[0] = r.blk0[0] = 0;
   long long off = 0;

@@ -299,7 +299,7 @@ extern "C" int vqa_slab_reduce(const float* ws, float* dw, int nslabs, long long
 
 static int stem_wgrad_grid(int B, int Ho, int Wo, size_t* shm_out) {
   int nsplit = Wo > 64 ? 2 : 1;
-  { static int env = -1; if (env < 0) { const char* e = getenv("VQA_STEM_NSPLIT"); env = e ? atoi(e) : 0; } if (env > 0 && Wo % (8 * env) == 0) nsplit = env; }
+  { const int env = vqa_env_int("VQA_STEM_NSPLIT", 0); if (env > 0 && Wo % (8 * env) == 0) nsplit = env; }
   const int PW = 2 * Wo + 8, MP = (Wo / nsplit + 31) / 32 * 32;
   const size_t shm = (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
   if (shm_out) *shm_out = shm;
@@ -310,8 +310,7 @@ static int stem_wgrad_grid(int B, int Ho, int Wo, size_t* shm_out) {
 }
 
 static int stem_nsplit(int Wo) {
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("VQA_STEM_NSPLIT"); env = e ? atoi(e) : 0; }
+  const int env = vqa_env_int("VQA_STEM_NSPLIT", 0);
   if (env > 0 && Wo % (8 * env) == 0) return env;
   return Wo > 64 ? 2 : 1;
 }

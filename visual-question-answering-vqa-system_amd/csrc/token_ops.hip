@@ -786,7 +786,7 @@ struct LnBwdGeom { int nb; bool colsum; unsigned gx, gy; size_t N; };
 static LnBwdGeom ln_bwd_geom(int dtype, int rows, int D, int period) {
   LnBwdGeom g = {0, false, 0, 0, 0};
   if (dtype && D % 8 == 0) {                                 // 8 waves per block, ~2 rows per wave (4+ rows left 10 240-row tensors latency-bound: 13 us for 15 MB)
-    static const int rpb = getenv("VQA_LN_BWD_ROWS") ? atoi(getenv("VQA_LN_BWD_ROWS")) : 16;
+    const int rpb = vqa_env_int("VQA_LN_BWD_ROWS", 16);
     g.nb = (rows + rpb - 1) / rpb; if (g.nb > 1024) g.nb = 1024;
   }
   else g.nb = (rows + 15) / 16 > 2048 ? 2048 : (rows + 15) / 16;

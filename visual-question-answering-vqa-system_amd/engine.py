@@ -10,7 +10,6 @@ RCCL all-reduce (on its own stream, after `events`) while earlier layers are sti
 from __future__ import annotations
 
 import math
-import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -42,18 +41,17 @@ class HipEngine:
         self._wt_plan: Dict[str, tuple] = {}      # operands packed by begin_step (filled by _packT on first use)
         self._wt_table = None
         self._wt_buf = None
-        self.defer_tail = os.environ.get("VQA_DEFER_TAIL", "1") != "0"
-        # BatchNorm-backward column sums reduced inside the data-gradient epilogues (igemm bnred=...): built and parity-tested, but
-        # measured SLOWER in the step (the serial epilogue of a compute-bound tile is a poor place for a streaming reduction:
-        # +0.5 ms of igemm time for 0.4 ms of reduce passes saved at B=512), so it is an opt-in measurement switch
-        self.fuse_bn_reduce = os.environ.get("VQA_BNRED", "0") == "1"
+        # schedule switches: plain attributes (tools/ flip them for A/B measurements); the product never reads the environment
+        self.defer_tail = True
         self._deferred = []
         self._wgq = []
-        self.group_wgrad = os.environ.get("VQA_WGRAD_GROUP", "1") != "0"
+        self.group_wgrad = True
         self._foldq = []                          # deferred folds of the LayerNorm / bias parameter gradients (K.fold_group at segment end)
         self._foldq2 = []
-        self.defer_folds = os.environ.get("VQA_DEFER_FOLDS", "1") != "0"
-        self.bias_offpath = os.environ.get("VQA_BIAS_OFFPATH", "0") != "0"
+        self.defer_folds = True
+        self.bias_offpath = False
+        self.use_c64_fwd = False                  # 4-wave stage-1 patch kernel for forward / data gradient (superseded by the 8-wave one)
+        self.use_c64p = True                      # 8-wave weights-resident stage-1 conv kernel
         self._stem_fcoef = None
         self.fold_eval = True                     # inference (eval, no tape): Conv+BN folded, BN never runs as its own pass
         self._fold = None                         # (key, table, nd, blocks, wbuf, bbuf, views)
@@ -188,7 +186,7 @@ class HipEngine:
                               self.buf[prefix + ".running_mean"], self.buf[prefix + ".running_var"])
 
     def _c64_ok(self, B, H, W, Cin, Cout, R, stride, wgrad=False):
-        if not wgrad and not os.environ.get("VQA_C64FWD"):
+        if not wgrad and not self.use_c64_fwd:
             return False          # since the LDS-DMA rewrite the generic implicit GEMM is as fast for forward / data gradient
         return (self.dtype == torch.bfloat16 and Cin == 64 and Cout == 64 and R == 3 and stride == 1 and K.c64_blocks(B, H, W) > 0)
 
@@ -200,7 +198,7 @@ class HipEngine:
         """64 -> 64 channel 3x3/1 conv without epilogue inputs: the 8-wave LDS-DMA patch kernel (156 vs 215 us forward, 152 vs 188 us
         data gradient at B=512)."""
         return (self.dtype == torch.bfloat16 and Cin == 64 and Cout == 64 and R == 3 and stride == 1 and K.c64p_blocks(B, H, W) > 0
-                and os.environ.get("VQA_C64P", "1") != "0")
+                and self.use_c64p)
 
     def _wflip(self, name):                  # [Cin][(2-r,2-s)][Cout] operand of the stride-1 data gradient as a plain 3x3 conv
         e = self.E[name]
@@ -873,17 +871,13 @@ class HipEngine:
         else:
             self._off_path([dy2], lambda: K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T))
         slab1, nb1 = None, 0
-        if self._c64p_ok(B, Ho, Wo, Cout, Cout, 3, 1) and not self.fuse_bn_reduce:
+        if self._c64p_ok(B, Ho, Wo, Cout, Cout, 3, 1):
             da1, _, _ = K.conv3x3_c64p(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
         elif c64_2:
             da1, _, _ = K.conv3x3_c64(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
         else:
             geom_d2 = (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
-            # bn1's backward column sums (g = da1 * [relu(bn1(y1)) > 0]) are reduced in this launch's epilogue
-            da1, slab1, nb1 = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1,
-                                      bnred=(rec["y1"], rec["c1"], True) if self.fuse_bn_reduce else None)
-            if not self.fuse_bn_reduce:
-                slab1, nb1 = None, 0
+            da1, _, _ = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1)
         dy1, _ = K.bn_bwd(da1, None, rec["y1"], rec["c1"], self.P(p + ".bn1.weight"), Cout, training,
                           gs(p + ".bn1.weight"), gs(p + ".bn1.bias"), self_mask=True,      # a1 > 0 recomputed from y1: a1 is not read
                           slab=slab1, nb=nb1)
@@ -912,11 +906,6 @@ class HipEngine:
         elif c64_1 and not masked and outmask is None:
             dx, _, _ = K.conv3x3_c64(dy1, self._wflip(p + ".conv1.weight"), B, H, W, addend=dout, addmask=rec["out"])
         else:
-            bnred = None
-            if hand is not None and self.fuse_bn_reduce:      # previous block's bn2 (and its 1x1-shortcut BN): sums reduced here
-                bnred = (hand["y2"], hand["c2"], False) + ((hand["yd"], hand["cd"]) if "yd" in hand else ())
-            dx, slabp, nbp = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
-                                     addend=dout, addmask=out_act, outmask=outmask, bnred=bnred)
-            if bnred is not None:
-                return dx, (slabp, nbp)
+            dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
+                               addend=dout, addmask=out_act, outmask=outmask)
         return dx, None

@@ -89,16 +89,7 @@ def igemm_variant(dtype, loader, M, N, Kw, geom) -> int:
 def igemm_symbol(dtype, loader, var) -> str:
     """Kernel symbol as rocprofv3 prints it: igemm_kernel<T, BM, BN, LOADER, waves, BK, waves/SIMD, ring slots, window loader>."""
     bm, bn, fl = var // 10000, (var % 10000) // 10, var % 10
-    nw, bk, occ, st, win = 4, _bk(dtype), 2, 2, 0
-    if fl == 1:
-        win = 1
-    elif fl in (2, 3):
-        nw, st = 8, fl
-    elif fl == 4:
-        nw, bk = 2, 32
-    elif fl == 5:
-        bk, occ = 32, 3
-    return f"igemm_kernel<{_tname(dtype)}, {bm}, {bn}, {loader}, {nw}, {bk}, {occ}, {st}, {win}>"
+    return f"igemm_kernel<{_tname(dtype)}, {bm}, {bn}, {loader}, 4, {_bk(dtype)}, 2, 2, {1 if fl == 1 else 0}>"
 
 
 def _tname(dtype):
@@ -252,11 +243,9 @@ def stem_conv(img, wstem, B, H, W, want_stats):
 
 
 def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=None, addmask=None, outmask=None, want_stats=False,
-          transposed=0, relu=0, drop_p=0.0, drop_seed=0, out=None, bnred=None):
+          transposed=0, relu=0, drop_p=0.0, drop_seed=0, out=None):
     """out[M][N] = gather(a) @ w[N][Kw]^T with the fused epilogue.  geom = (B, H, W, C, Ho, Wo, R, S, stride, pad).
-    Returns (out, stats_slab | None, mtiles).
-    bnred = (y, coef, self_mask[, y2, coef2]): data-gradient launches only -- the BatchNorm-backward column sums of the stored
-    gradient against the conv output y are reduced in the epilogue; the slab [mtiles][3][N] is returned in place of stats."""
+    Returns (out, stats_slab | None, mtiles)."""
     B, H, W, C, Ho, Wo, R, S, stride, pad = geom
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=dtype)
@@ -264,22 +253,11 @@ def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=
     if want_stats:
         mt = L.count("vqa_igemm_mtiles", M, N, loader)
         stats = torch.empty((mt, 2, N), device=a.device, dtype=torch.float32)
-    bn_y = bn_coef = bn_y2 = bn_coef2 = None
-    bn_self = 0
-    if bnred is not None:
-        assert not want_stats
-        bn_y, bn_coef, bn_self = bnred[0], bnred[1], int(bnred[2])
-        if len(bnred) > 3:
-            bn_y2, bn_coef2 = bnred[3], bnred[4]
-        mt = L.count("vqa_igemm_mtiles", M, N, loader)
-        stats = torch.empty((mt, 3, N), device=a.device, dtype=torch.float32)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("vqa_igemm", dt(dtype), loader, ptr(a), ptr(w), ptr(out), ptr(bias), ptr(addend), ptr(addmask), ptr(outmask),
-         ptr(stats) if bnred is None else None,
-         M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad, transposed, relu, float(drop_p), int(drop_seed),
-         ptr(bn_y), ptr(bn_coef), ptr(bn_y2), ptr(bn_coef2), ptr(stats) if bnred is not None else None, bn_self)
+    call("vqa_igemm", dt(dtype), loader, ptr(a), ptr(w), ptr(out), ptr(bias), ptr(addend), ptr(addmask), ptr(outmask), ptr(stats),
+         M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad, transposed, relu, float(drop_p), int(drop_seed))
     if PROFILE is not None:
         e1.record()
         var = igemm_variant(dtype, loader, M, N, Kw, geom)
@@ -393,7 +371,7 @@ def bn_bwd(dout, outact, y, coef, gamma, C, training, dgamma, dbeta, y2=None, co
     self_mask: the ReLU directly follows this BN (no residual), so the mask relu(bn(y)) > 0 is recomputed from y and the
     activation tensor is not read at all (pass outact=None).  Returns dy (and dy2)."""
     rows = y.numel() // C
-    if slab is None:           # (else: the producer of dout already reduced the column sums in its epilogue, igemm(bnred=...))
+    if slab is None:           # (else: the caller already reduced the column sums)
         nb = L.count("vqa_bn_bwd_blocks", rows)
         slab = torch.empty((nb, 3, C), device=y.device, dtype=torch.float32)
         call("vqa_bn_bwd_reduce", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(coef), ptr(y2), ptr(coef2), ptr(slab), rows, C, int(self_mask))
