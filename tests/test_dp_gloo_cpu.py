@@ -75,7 +75,7 @@ def _worker_force(rank, world, port, q):
     issued = list(red.issued)
     scale = red.finish()
     q.put((rank, (not idle.active) and idle.bytes_reduced == 0 and red.active and red.bytes_reduced == 4 * n + 4
-           and torch.equal(G, mine) and int(bad) == 3 and scale == 1.0 and len(issued) == len(red.buckets), issued))
+           and torch.equal(G, mine) and int(bad) == 3 and scale == 1.0 and len(issued) == len(red.groups) == 4, issued))
     dist.destroy_process_group()
 
 
@@ -88,7 +88,9 @@ def test_forced_reducer_runs_every_bucket_in_a_world_of_one():
     rank, ok, issued = q.get(timeout=120)
     p.join(timeout=60)
     assert p.exitcode == 0 and ok
-    assert issued[0] == "answer_head" and issued[-1] == "image_encoder.stem"
+    # adjacent segments travel as one message: head + fusion + text encoder first, stage 2 + stage 1 + stem last
+    assert issued[0] == "answer_head+fusion+text_encoder" and issued[1] == "image_encoder.stage4"
+    assert issued[-1] == "image_encoder.stage2+image_encoder.stage1+image_encoder.stem"
 
 
 def test_forced_reducer_needs_a_process_group():

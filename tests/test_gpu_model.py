@@ -272,3 +272,50 @@ def test_attention_maps_follow_num_image_tokens():
     with torch.no_grad():
         maps = m.get_attention_maps(images.to(DEV), ids.to(DEV), mask.to(DEV))
     assert maps["cross_attention_spatial"].shape == (2, 10, 12, 12)
+
+
+def test_train_bf16_gradients_at_batch64_against_the_fp32_oracle():
+    """Whole-model bf16 gradients at B=64 against autograd of the fp32 CPU oracle, every parameter tensor bounded (no exemptions):
+        token side (text encoder, fusion, answer head -- 120 tensors): relative L2 error <= 0.25   (measured <= 0.163)
+        CNN tensors: <= 0.75, whole-model vector <= 0.45                                       (measured <= 0.533 / 0.32)
+    The CNN figure is the noise floor of bf16 ITSELF on this model at random init (PyTorch's own CPU bf16 autocast sits at 0.4-0.55,
+    tests/_bf16check.py) and does not shrink with the batch (B = 8 and B = 64 measure the same: the batch gradient is the small
+    residual of per-sample gradients that cancel) -- so the CNN path is held to 4e-3 per LAYER by tests/test_gpu_insitu.py on the
+    live tape of this very configuration instead, and this test keeps the end-to-end view."""
+    torch.set_num_threads(16)
+    B = 64
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0)
+    sd = O.init_state_dict(cfg, 7, jitter=True)
+    images, ids, mask, answers = O.synthetic_batch(B, seed=77)
+    tr = O.OracleTrainer(sd, cfg)
+    lo, _ = O.vqa_forward(images, ids, mask, tr.sd, cfg, True, {})
+    lref = torch.nn.functional.cross_entropy(lo, answers)
+    lref.backward()
+    m = _model(cfg, sd, "bf16").train()
+    logits, _ = m(images.to(DEV), ids.to(DEV), mask.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits, answers.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - lref.item()) < 2e-2 and (logits.cpu() - lo.detach()).abs().max().item() < 5e-2
+    P = dict(m.named_parameters())
+    names = O.parameter_names(cfg)
+    worst_tok, worst_cnn = ("", 0.0), ("", 0.0)
+    gs, rs = [], []
+    for n in names:
+        r = tr.sd[n].grad.float().reshape(-1)
+        g = P[n].grad.detach().float().cpu().reshape(-1)
+        gs.append(g); rs.append(r)
+        if float(r.norm()) < 1e-10:
+            assert float(g.norm()) < 1e-6, n
+            continue
+        e = float((g - r).norm() / r.norm())
+        if n.startswith("image_encoder."):
+            worst_cnn = max(worst_cnn, (n, e), key=lambda t: t[1])
+            assert e <= 0.75, (n, e)
+        else:
+            worst_tok = max(worst_tok, (n, e), key=lambda t: t[1])
+            assert e <= 0.25, (n, e)
+    G, R = torch.cat(gs), torch.cat(rs)
+    whole = float((G - R).norm() / R.norm())
+    assert whole <= 0.45, whole
+    print("worst token-side", worst_tok, "worst CNN", worst_cnn, "whole model", whole)

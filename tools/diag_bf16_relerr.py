@@ -12,6 +12,8 @@ torch.set_num_threads(16)
 cfg = O.full_config(dropout=0.0, answer_dropout=0.0)
 sd = O.init_state_dict(cfg, 7, jitter=True)
 images, ids, mask, answers = O.synthetic_batch(B, seed=77)
+if len(sys.argv) > 3 and sys.argv[3] == "same":       # a coherent signal: every sample pulls towards the same class (reproduce_issue.py's targets)
+    answers[:] = 1
 names = O.parameter_names(cfg)
 tr = O.OracleTrainer(sd, cfg)
 lo, _ = O.vqa_forward(images, ids, mask, tr.sd, cfg, True, {})
@@ -31,7 +33,7 @@ for n in names:
     rn = float(ref[n].norm())
     rows.append((float((g - ref[n]).norm()) / max(rn, 1e-30), n, rn, P[n].dim()))
 print(f"B={B} {dtype} loss ref {float(loss):.5f} hip {float(l2):.5f} logits maxdiff {float((logits.cpu() - lo).abs().max()):.4f}")
-for e, n, rn, d in sorted(rows, reverse=True)[:40]:
+for e, n, rn, d in sorted(rows, reverse=True)[:(400 if os.environ.get('DIAG_ALL') else 40)]:
     print(f"{e:8.4f}  dim{d}  |g|={rn:9.3e}  {n}")
 G = torch.cat([P[n].grad.detach().float().cpu().reshape(-1) for n in names]); R = torch.cat([ref[n] for n in names])
 print("whole-model relerr", float((G - R).norm() / R.norm()), " max over >=2-D:", max(e for e, n, rn, d in rows if d >= 2), " max over 1-D:", max(e for e, n, rn, d in rows if d < 2))

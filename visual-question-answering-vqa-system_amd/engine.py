@@ -61,6 +61,9 @@ class HipEngine:
         self.side2 = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None   # CNN weight gradients (off the critical path)
         self.two_streams = True
         self.wgrad_stream = True
+        # test hook (tests/test_gpu_insitu.py): a dict here receives, per residual block, the intermediate gradients of its backward
+        # (dout, dy2, dyd, da1, dy1, dx) so that every layer of a LIVE full-size bf16 step can be checked locally against fp32 math
+        self.capture = None
 
     # ------------------------------------------------------------------ parameter access
     def P(self, name):                       # fp32 master, flat 1-D
@@ -908,4 +911,6 @@ class HipEngine:
         else:
             dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
                                addend=dout, addmask=out_act, outmask=outmask)
+        if self.capture is not None:
+            self.capture[p] = dict(dout=dout, masked=masked, handed=hand is not None, dy2=dy2, dyd=dyd, da1=da1, dy1=dy1, dx=dx)
         return dx, None

@@ -18,8 +18,22 @@ from . import layout as LY
 from ._lib import call, dt, ptr
 
 
+# Gradient segments (layout.bucket_ranges, reported by engine.backward in this order: answer_head, fusion, text_encoder, stage4 ...
+# stem) are all-reduced in FOUR collectives: adjacent segments that finish close together travel as one message.
+#   * head + fusion + text encoder (29.6 MB): the first two finish inside the latency-bound fusion chain right after the forward
+#     (~120 dependent launches of 4-40 us).  Issuing a collective there costs host time exactly where the GPU is waiting for the
+#     next launch (measured with a one-rank RCCL group at B=512: 9 collectives, three of them inside the chain: +0.9 ms per step);
+#     merged, the message leaves when the text encoder's backward (side stream) reports, while the stage-4 convolutions run;
+#   * stage 4 (33.7 MB) and stage 3 (8.4 MB): one message each, in flight under the stage-3 ... stem backward;
+#   * stage 2 + stage 1 + stem (2.7 MB): one message at the end, together with the 4-byte bad-target counter.
+# Larger messages also suit xGMI: a ring / direct all-reduce is per-link bound (7 links x ~153 GB/s per GPU), and a 2 MB message
+# is mostly latency.
+BUCKET_GROUPS = (("answer_head", "fusion", "text_encoder"), ("image_encoder.stage4",), ("image_encoder.stage3",),
+                 ("image_encoder.stage2", "image_encoder.stage1", "image_encoder.stem"))
+
+
 class GradBucketReducer:
-    """Sum-all-reduce of contiguous gradient buckets, issued bucket by bucket while backward is still running.
+    """Sum-all-reduce of contiguous gradient buckets, issued group by group while backward is still running.
     Device-agnostic (CUDA tensors: side stream + events, RCCL; CPU tensors: gloo) so the N>1 logic is testable on CPU."""
 
     def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, overlap=True, force=False):
@@ -29,6 +43,23 @@ class GradBucketReducer:
         self.G = flat_grad
         self.buckets = list(buckets)
         self._range = {name: (lo, hi) for name, lo, hi in self.buckets}
+        # merged groups: name -> (group index); a group is issued when its last segment has been reported
+        self.groups = []
+        for g in BUCKET_GROUPS:
+            names = [n for n in g if n in self._range]
+            if not names:
+                continue
+            lo, hi = min(self._range[n][0] for n in names), max(self._range[n][1] for n in names)
+            if sum(self._range[n][1] - self._range[n][0] for n in names) != hi - lo:
+                raise RuntimeError(f"gradient segments {names} are not adjacent in the flat buffer")
+            self.groups.append((names, lo, hi))
+        grouped = {n for names, _, _ in self.groups for n in names}
+        for name, lo, hi in self.buckets:              # (a segment outside the table travels alone)
+            if name not in grouped:
+                self.groups.append(([name], lo, hi))
+        self._group_of = {n: i for i, (names, _, _) in enumerate(self.groups) for n in names}
+        self._pending = {}                             # group index -> (segments still missing, events collected)
+        self._aux: List = []
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         if force and not (dist.is_available() and dist.is_initialized()):
@@ -58,10 +89,10 @@ class GradBucketReducer:
         self.bytes_reduced += tensor.numel() * tensor.element_size()
 
     def reduce_aux(self, tensor: torch.Tensor):
-        """Sum a small side tensor (the per-step bad-target counter) over the ranks; ordered after everything enqueued so far on
-        the current stream, waited for in finish() with the gradient buckets."""
+        """Sum a small side tensor (the per-step bad-target counter) over the ranks: issued behind the last gradient message of
+        the step (ordered after everything enqueued on the current stream by then), waited for in finish() with the buckets."""
         if self.active:
-            self._issue(tensor)
+            self._aux.append(tensor)                   # travels with the LAST group: no collective inside the latency-bound chain
 
     def on_segment(self, name: str, events=()):
         """`events`: HIP events after which every gradient kernel of this segment has been enqueued-and-ordered (the engine
@@ -70,12 +101,33 @@ class GradBucketReducer:
         keeps running ahead of the weight gradients exactly as in the 1-GPU step."""
         if not self.active or name not in self._range:
             return
-        lo, hi = self._range[name]
-        self.issued.append(name)
-        self._issue(self.G[lo:hi], events)
+        gi = self._group_of[name]
+        names, lo, hi = self.groups[gi]
+        missing, evs = self._pending.get(gi, (set(names), []))
+        missing.discard(name)
+        evs = evs + list(events)
+        if self.G.is_cuda:                             # the stream that reports the segment (main, or the text encoder's side stream)
+            e = torch.cuda.Event()
+            e.record()
+            evs.append(e)
+        if missing:
+            self._pending[gi] = (missing, evs)
+            return
+        self._pending.pop(gi, None)
+        self.issued.append("+".join(names))
+        self._issue(self.G[lo:hi], evs)
+        if len(self.issued) == len(self.groups):       # the last message of the step: the side tensors ride behind it
+            for t in self._aux:
+                self._issue(t)
+            self._aux = []
 
     def finish(self):
         """Make the current stream (or the host, for gloo) wait for every bucket; returns the 1/world gradient scale."""
+        if self._pending:
+            raise RuntimeError(f"gradient segments never reported: {[sorted(m) for m, _ in self._pending.values()]}")
+        for t in self._aux:                            # (a backward that reports no final group: still reduce the side tensors)
+            self._issue(t)
+        self._aux = []
         for w in self._works:
             w.wait()
         self._works = []
