@@ -104,6 +104,12 @@ int vqa_bn_eval_coef(int C, const float* gamma, const float* beta, const float* 
 /* out = [relu](y*scale+shift [+ res | + res*rscale+rshift])   -- BN + residual add + ReLU (cnn_backbone.py:186-195) */
 int vqa_bn_apply(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, void* out,
                  long long numel, int C, int relu, hipStream_t stream);
+/* the same for the LAST residual block of a stage, with the squeeze-excitation global-average-pool sums folded in: also writes the
+   column sums of the stored values per (sample, row chunk) to part[B][vqa_bn_apply_pool_chunks()][C]; vqa_se_fwd(pool_part = part)
+   folds them instead of re-reading the stage output (models/cnn_backbone.py:194-197 -> models/attention_modules.py:109-112) */
+int vqa_bn_apply_pool_chunks(int dtype, int HW, int C);
+int vqa_bn_apply_pool(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, void* out, int B, int HW, int C,
+                      int relu, float* part, hipStream_t stream);
 int vqa_bn_bwd_blocks(long long rows);
 int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const void* y, const float* coef, const void* y2,
                       const float* coef2, float* slab /* [blocks][3][C] */, long long rows, int C, int self_mask /* mask = relu(bn(y))>0 from y */,
@@ -123,10 +129,16 @@ int vqa_stem_bwd_apply(int dtype, const void* dpool, const uint8_t* idx, const v
 
 /* ---- SEAttention.forward (models/attention_modules.py:109-136) and its backward ---------------------------------- */
 int vqa_se_fwd(int dtype, const void* x, const float* w1, const float* w2, float* pooled, float* hidden, float* scale,
-               void* out, int B, int HW, int C, int Cr, hipStream_t stream);
+               void* out, int B, int HW, int C, int Cr,
+               const float* pool_part /* or NULL: pool x here */, int pool_chunks /* = vqa_bn_apply_pool_chunks */, hipStream_t stream);
+/* bn_y / bn_coef / bn_slab (all or none): dx is the gradient entering the BatchNorm whose conv output is bn_y (the stage's last bn2);
+   its backward column sums sum dx | sum dx*xhat(bn_y) are written to bn_slab[vqa_se_bwd_blocks()][3][C] (the layout
+   vqa_bn_bwd_finalize reads) in the same pass, so the caller skips vqa_bn_bwd_reduce for that BatchNorm */
+int vqa_se_bwd_blocks(int dtype, int B, int HW, int C);
 int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, const float* w2, const float* pooled,
                const float* hidden, const float* scale, float* scratch /* B*(2C+Cr) */, void* dx, float* dw1, float* dw2,
-               int B, int HW, int C, int Cr, int mask_out /* dx *= (x > 0): x is a post-ReLU activation */, hipStream_t stream);
+               int B, int HW, int C, int Cr, int mask_out /* dx *= (x > 0): x is a post-ReLU activation */,
+               const void* bn_y, const float* bn_coef, float* bn_slab, hipStream_t stream);
 /* ---- SpatialAttention.forward (models/attention_modules.py:223-243) and its backward ----------------------------- */
 int vqa_spatial_fwd(int dtype, const void* x, const float* w /* (1,2,7,7) */, float* pooled2, int* argmax, float* amap,
                     void* out, int B, int H, int W, int C, hipStream_t stream);

@@ -1,0 +1,154 @@
+"""GPU: the two pass-fusions around squeeze-excitation (SEAttention.forward, models/attention_modules.py:109-136, behind the stage's
+last ResidualBlock, models/cnn_backbone.py:186-197), each against the unfused kernels (bit-equal tensors) and against torch math:
+
+  vqa_bn_apply_pool   bn2 + residual + ReLU of the last block, ALSO leaving the SE global-average-pool sums per (sample, row chunk)
+                      -> vqa_se_fwd(pool_part=...) skips its pooling pass;
+  vqa_se_bwd(bn_*)    the SE backward apply pass ALSO leaving the BatchNorm-backward column sums of the gradient it stores
+                      -> the last block's vqa_bn_bwd_reduce is skipped.
+Shapes: the four stage outputs of the benchmark (56x56x64 ... 7x7x512) at a small batch, plus ragged sizes (rows not a multiple of
+the chunk, one chunk only), both dtypes.  The whole-model goldens (tests/test_gpu_model.py) run with both fusions on (default)."""
+import pytest
+import torch
+
+from _pkg import sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SHAPES = [(6, 56 * 56, 64), (5, 28 * 28, 128), (4, 14 * 14, 256), (3, 7 * 7, 512), (2, 15 * 15, 64), (3, 3 * 3, 128)]
+
+
+def _coef(C, g):            # scale | shift | mean | invstd
+    return torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.2,
+                        torch.rand(C, generator=g) + 0.5])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_bn_apply_pool_equals_bn_apply_plus_pooling(shape, dtype):
+    L, K = sub("_lib"), sub("kernels")
+    B, HW, C = shape
+    Cr = max(C // 16, 1)
+    g = torch.Generator().manual_seed(HW + C)
+    y = torch.randn(B * HW, C, generator=g).to(DEV, dtype)
+    res = torch.randn(B * HW, C, generator=g).to(DEV, dtype)
+    coef = _coef(C, g).to(DEV)
+    w1 = (torch.randn(Cr, C, generator=g) * 0.2).to(DEV)
+    w2 = (torch.randn(C, Cr, generator=g) * 0.2).to(DEV)
+    ref_out = K.bn_apply(y, coef, C, relu=True, res=res)
+    out, part, chunks = K.bn_apply_pool(y, coef, C, True, B, HW, res=res)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out)                                        # the stored activation is unchanged, bit for bit
+    assert part.shape == (B, chunks, C) and chunks == L.count("vqa_bn_apply_pool_chunks", L.dt(dtype), HW, C)
+    sums = out.float().view(B, HW, C).sum(1)
+    assert (part.sum(1) - sums).abs().max().item() < 1e-4 * max(1.0, sums.abs().max().item())
+    # SE forward fed with the partial sums == SE forward that pools by itself
+    def se(pool):
+        pooled = torch.empty(B, C, device=DEV); hidden = torch.empty(B, Cr, device=DEV); scale = torch.empty(B, C, device=DEV)
+        o = torch.empty_like(out)
+        L.call("vqa_se_fwd", L.dt(dtype), out.data_ptr(), w1.data_ptr(), w2.data_ptr(), pooled.data_ptr(), hidden.data_ptr(), scale.data_ptr(),
+               o.data_ptr(), B, HW, C, Cr, part.data_ptr() if pool else None, chunks if pool else 0)
+        return o, pooled, scale
+    a, pa, sa = se(True)
+    b, pb, sb = se(False)
+    torch.cuda.synchronize()
+    assert (pa - pb).abs().max().item() < 1e-5 * max(1.0, pb.abs().max().item())
+    assert (sa - sb).abs().max().item() < 1e-5
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert (a.float() - b.float()).abs().max().item() <= tol * max(1.0, b.float().abs().max().item())
+    # and the torch formula of SEAttention.forward
+    xf = out.float().view(B, HW, C)
+    ref = xf * torch.sigmoid(torch.relu(xf.mean(1) @ w1.t()) @ w2.t())[:, None, :]
+    assert (a.float().view(B, HW, C) - ref).abs().max().item() < (2e-2 if dtype == torch.bfloat16 else 1e-4) * max(1.0, ref.abs().max().item())
+    # variants without / with the shortcut BatchNorm as residual keep working
+    out0, part0, _ = K.bn_apply_pool(y, coef, C, True, B, HW)
+    assert torch.equal(out0, K.bn_apply(y, coef, C, relu=True))
+    rc = _coef(C, g).to(DEV)
+    out2, _, _ = K.bn_apply_pool(y, coef, C, True, B, HW, res=res, rcoef=rc)
+    assert torch.equal(out2, K.bn_apply(y, coef, C, relu=True, res=res, rcoef=rc))
+    with pytest.raises(RuntimeError):                                       # a chunk count that does not match the shape is refused
+        pooled = torch.empty(B, C, device=DEV)
+        L.call("vqa_se_fwd", L.dt(dtype), out.data_ptr(), w1.data_ptr(), w2.data_ptr(), pooled.data_ptr(), pooled.data_ptr(), pooled.data_ptr(),
+               out0.data_ptr(), B, HW, C, Cr, part.data_ptr(), chunks + 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_se_backward_leaves_the_batchnorm_backward_sums(shape, dtype):
+    L = sub("_lib")
+    B, HW, C = shape
+    Cr = max(C // 16, 1)
+    g = torch.Generator().manual_seed(HW * 3 + C)
+    x = torch.relu(torch.randn(B * HW, C, generator=g)).to(DEV, dtype)       # SE input = a post-ReLU activation
+    dout = torch.randn(B * HW, C, generator=g).to(DEV, dtype)
+    y2 = torch.randn(B * HW, C, generator=g).to(DEV, dtype)
+    coef = _coef(C, g).to(DEV)
+    w1 = (torch.randn(Cr, C, generator=g) * 0.2).to(DEV)
+    w2 = (torch.randn(C, Cr, generator=g) * 0.2).to(DEV)
+    pooled = x.float().view(B, HW, C).mean(1).contiguous()
+    hidden = torch.relu(pooled @ w1.t()).contiguous()
+    scale = torch.sigmoid(hidden @ w2.t()).contiguous()
+
+    def run(fused):
+        scratch = torch.empty(B * (2 * C + Cr), device=DEV)
+        dx = torch.empty_like(x)
+        dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+        nblk = L.count("vqa_se_bwd_blocks", L.dt(dtype), B, HW, C)
+        slab = torch.full((nblk, 3, C), float("nan"), device=DEV) if fused else None
+        L.call("vqa_se_bwd", L.dt(dtype), dout.data_ptr(), x.data_ptr(), w1.data_ptr(), w2.data_ptr(), pooled.data_ptr(), hidden.data_ptr(),
+               scale.data_ptr(), scratch.data_ptr(), dx.data_ptr(), dw1.data_ptr(), dw2.data_ptr(), B, HW, C, Cr, 1,
+               y2.data_ptr() if fused else None, coef.data_ptr() if fused else None, slab.data_ptr() if fused else None)
+        return dx, dw1, dw2, slab
+    dx, dw1, dw2, slab = run(True)
+    dx0, dw10, dw20, _ = run(False)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx0) and torch.equal(dw1, dw10) and torch.equal(dw2, dw20)      # the fused reduction changes nothing else
+    assert torch.isfinite(slab).all()
+    gq = dx.float()
+    ref0 = gq.sum(0)
+    ref1 = (gq * (y2.float() - coef[2]) * coef[3]).sum(0)
+    s = slab.sum(0)
+    tol = lambda r: 2e-4 * float(r.abs().max()) + 1e-4
+    assert (s[0] - ref0).abs().max().item() < tol(ref0) and (s[1] - ref1).abs().max().item() < tol(ref1)
+    assert float(s[2].abs().max()) == 0.0
+    # the same sums from the standalone reduce kernel (what the unfused schedule runs on the stored gradient)
+    nb = L.count("vqa_bn_bwd_blocks", B * HW)
+    slab2 = torch.empty(nb, 3, C, device=DEV)
+    L.call("vqa_bn_bwd_reduce", L.dt(dtype), dx.data_ptr(), None, y2.data_ptr(), coef.data_ptr(), None, None, slab2.data_ptr(), B * HW, C, 0)
+    torch.cuda.synchronize()
+    s2 = slab2.sum(0)
+    assert (s[0] - s2[0]).abs().max().item() < tol(ref0) and (s[1] - s2[1]).abs().max().item() < tol(ref1)
+    with pytest.raises(RuntimeError):                                       # all three BatchNorm arguments or none
+        scratch = torch.empty(B * (2 * C + Cr), device=DEV)
+        L.call("vqa_se_bwd", L.dt(dtype), dout.data_ptr(), x.data_ptr(), w1.data_ptr(), w2.data_ptr(), pooled.data_ptr(), hidden.data_ptr(),
+               scale.data_ptr(), scratch.data_ptr(), dx.data_ptr(), dw1.data_ptr(), dw2.data_ptr(), B, HW, C, Cr, 1, y2.data_ptr(), None, None)
+
+
+def test_engine_runs_the_fused_schedule_and_matches_the_unfused_one():
+    """One fp32 train step of the full model with both fusions on (default) and off: same loss, gradients equal up to the fp32
+    summation order of the pooled / reduced sums (nothing else differs; fp32 so that a last-bit difference is not amplified by
+    bf16 re-rounding downstream), and the fused schedule really skips the two passes."""
+    from _pkg import pkg
+    from oracle import vqa_oracle as O
+    P = pkg()
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0)
+    sd = O.init_state_dict(cfg, 3, jitter=True)
+    batch = [t.to(DEV) for t in O.synthetic_batch(6, seed=9)]
+    K = sub("kernels")
+    res = {}
+    for fused in (True, False):
+        m = P.load_dropin().VQAModel(**cfg, compute_dtype="fp32")
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        tr = P.trainer.HipTrainer(m)
+        tr.engine.fuse_se_pool = tr.engine.fuse_se_bnred = fused
+        K.PROFILE = []
+        loss, _ = tr.step(*batch)
+        torch.cuda.synchronize()
+        names = [n for n, *_ in K.PROFILE]
+        K.PROFILE = None
+        res[fused] = (float(loss), tr.G.clone(), names)
+    (l1, g1, n1), (l0, g0, n0) = res[True], res[False]
+    assert sum(n.endswith(":bn_apply_pool") for n in n1) == 4 and sum(n.endswith(":bn_apply_pool") for n in n0) == 0
+    assert sum(n.endswith(":bn_bwd_reduce") for n in n0) - sum(n.endswith(":bn_bwd_reduce") for n in n1) == 4
+    assert abs(l1 - l0) < 1e-5
+    assert float((g1 - g0).norm() / g0.norm()) < 1e-3

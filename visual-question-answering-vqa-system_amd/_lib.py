@@ -46,6 +46,9 @@ SIGNATURES = {
     "vqa_bn_stats_finalize": [P, I, I, D, P, P, P, P, P, F, F, P, P, P],
     "vqa_bn_eval_coef": [I, P, P, P, P, F, P, P],
     "vqa_bn_apply": [I, P, P, P, P, P, LL, I, I, P],
+    "vqa_bn_apply_pool_chunks": [I, I, I],
+    "vqa_bn_apply_pool": [I, P, P, P, P, P, I, I, I, I, P, P],
+    "vqa_se_bwd_blocks": [I, I, I, I],
     "vqa_bn_bwd_blocks": [LL],
     "vqa_bn_bwd_reduce": [I, P, P, P, P, P, P, P, LL, I, I, P],
     "vqa_bn_bwd_finalize": [P, I, I, I, D, P, P, I, P, P, P, P],
@@ -53,8 +56,8 @@ SIGNATURES = {
     "vqa_stem_pool_fwd": [I, P, P, P, P, I, I, I, I, P],
     "vqa_stem_bwd_reduce": [I, P, P, P, P, P, I, I, I, I, P],
     "vqa_stem_bwd_apply": [I, P, P, P, P, P, P, I, I, I, I, P],
-    "vqa_se_fwd": [I, P, P, P, P, P, P, P, I, I, I, I, P],
-    "vqa_se_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "vqa_se_fwd": [I, P, P, P, P, P, P, P, I, I, I, I, P, I, P],
+    "vqa_se_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P],
     "vqa_spatial_fwd": [I, P, P, P, P, P, P, I, I, I, I, P],
     "vqa_spatial_bwd_scratch": [I, I, I],
     "vqa_spatial_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
@@ -90,7 +93,7 @@ SIGNATURES = {
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P, P, P],
 }
 _RET_LL = {"vqa_image_resize_ws", "vqa_wgrad_group_ws", "vqa_spatial_bwd_scratch", "vqa_layernorm_bwd_ws", "vqa_bias_act_bwd_ws"}                       # return a size (long long)
-_NO_STATUS = _RET_LL | {"vqa_wgrad3x3_c128_blocks", "vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
+_NO_STATUS = _RET_LL | {"vqa_bn_apply_pool_chunks", "vqa_se_bwd_blocks", "vqa_wgrad3x3_c128_blocks", "vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
 
 _lib = None
 

@@ -111,6 +111,52 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
   }
 }
 
+// The same map for the LAST residual block of a stage, with the squeeze-excitation global average pool folded in
+// (models/cnn_backbone.py:194-197 -> models/attention_modules.py:109-112): a workgroup owns rows [chunk*rpc, (chunk+1)*rpc) of ONE
+// sample and also writes the column sums of the values it stores (bf16-rounded, exactly what a pooling pass would read back) to
+// part[b][chunk][C]; se_pool_fc_kernel folds the chunks in index order.  Saves the pooling pass's read of the stage output.
+template <typename T, int RES>
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const T* __restrict__ y, const float* __restrict__ coef, const T* __restrict__ res,
+                                                            const float* __restrict__ rcoef, T* __restrict__ out, int HW, int C, int relu, int rpc,
+                                                            float* __restrict__ part) {
+  constexpr int VEC = Vec16<T>::N;
+  const int cv = C / VEC, lanes_r = 256 / cv;
+  const int c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
+  float sc[VEC], sh[VEC], rs[RES == 2 ? VEC : 1], rh[RES == 2 ? VEC : 1], acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = coef[c0 + j]; sh[j] = coef[C + c0 + j]; acc[j] = 0.f;
+    if (RES == 2) { rs[j] = rcoef[c0 + j]; rh[j] = rcoef[C + c0 + j]; }
+  }
+  const int b = blockIdx.y, r0 = blockIdx.x * rpc, r1 = min(HW, r0 + rpc);
+  const size_t base = (size_t)b * HW * C + c0;
+#pragma unroll 2
+  for (int r = r0 + myr; r < r1; r += lanes_r) {
+    const size_t off = base + (size_t)r * C;
+    Vec16<T> v = ldg16(y + off), rr, o;
+    if (RES) rr = ldg16(res + off);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float x = v.get(j) * sc[j] + sh[j];
+      if (RES == 1) x += rr.get(j);
+      if (RES == 2) x += rr.get(j) * rs[j] + rh[j];
+      o.set(j, (relu && x < 0.f) ? 0.f : x);
+      acc[j] += o.get(j);
+    }
+    stg16(out + off, o);
+  }
+  __shared__ float shs[256 * VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) shs[threadIdx.x * VEC + j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int v = c / VEC, j = c - v * VEC;
+    float t = 0.f;
+    for (int r = 0; r < lanes_r; ++r) t += shs[(r * cv + v) * VEC + j];
+    part[((size_t)b * gridDim.x + blockIdx.x) * C + c] = t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm backward.  g = dout * (out > 0) (relu) or dout.  Partial sums per block -> slab [blocks][3][C]:
 //   0: sum g   1: sum g*xhat(y)   2: sum g*xhat(y2) (second BN sharing g: the 1x1 shortcut)
@@ -366,7 +412,7 @@ __global__ void stem_bwd_apply_kernel(const T* __restrict__ dpool, const uint8_t
 template <typename T>
 __global__ __launch_bounds__(256) void se_pool_fc_kernel(const T* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ w2,
                                                          float* __restrict__ pooled, float* __restrict__ hidden, float* __restrict__ scale,
-                                                         int HW, int C, int Cr) {
+                                                         int HW, int C, int Cr, const float* __restrict__ part, int chunks) {
   constexpr int VEC = Vec16<T>::N;
   extern __shared__ float sh[];            // [256*VEC] scratch, then pooled[C], hidden[Cr]
   const int b = blockIdx.x, cv = C / VEC, lanes_r = 256 / cv;
@@ -374,7 +420,7 @@ __global__ __launch_bounds__(256) void se_pool_fc_kernel(const T* __restrict__ x
   float s[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s[j] = 0.f;
-  if (myr < lanes_r) {
+  if (!part && myr < lanes_r) {
     const T* xb = x + (size_t)b * HW * C + myv * VEC;
     int p = myr;
     for (; p + 3 * lanes_r < HW; p += 4 * lanes_r) {                 // 4 independent 16-byte loads in flight per thread
@@ -396,7 +442,8 @@ __global__ __launch_bounds__(256) void se_pool_fc_kernel(const T* __restrict__ x
   for (int c = threadIdx.x; c < C; c += 256) {
     const int v = c / VEC, j = c - v * VEC;
     float t = 0.f;
-    for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
+    if (part) { for (int k = 0; k < chunks; ++k) t += part[((size_t)b * chunks + k) * C + c]; }    // column sums left by bn_apply_pool_kernel
+    else { for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j]; }
     t /= (float)HW;
     pl[c] = t; pooled[(size_t)b * C + c] = t;
   }
@@ -506,20 +553,30 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
 // xmask != nullptr: dx is additionally multiplied by (xmask > 0).  xmask is the SE input = the post-ReLU output of the stage's
 // last residual block, so the block's backward receives its gradient ALREADY masked by its ReLU and never re-reads that
 // activation (BatchNorm-backward reduce + apply and the identity-path addend: three reads saved for one here).
-template <typename T>
+// BNRED (bn_y != nullptr): dx is the (masked) gradient entering the last block's bn2, so the BatchNorm-backward column sums
+// sum dx | sum dx*xhat(bn_y) over the pixels this workgroup stores go to bn_slab[blockIdx.x][3][C] (the layout
+// vqa_bn_bwd_finalize reads) -- the standalone reduce pass over dx and y2 is not run (one read of the stage output saved).
+template <typename T, bool BNRED>
 __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__ dout, const float* __restrict__ scale, const float* __restrict__ dpool,
                                                            T* __restrict__ dx, unsigned npix, int HW, int C, unsigned long long mul_hw,
-                                                           const T* __restrict__ xmask) {
+                                                           const T* __restrict__ xmask, const T* __restrict__ bn_y, const float* __restrict__ bn_coef,
+                                                           float* __restrict__ bn_slab) {
   constexpr int VEC = Vec16<T>::N;
   const float inv = 1.f / (float)HW;
   const int cv = C / VEC, lanes_r = 256 / cv, c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
+  float sg[BNRED ? VEC : 1], sx[BNRED ? VEC : 1], bmean[BNRED ? VEC : 1], binv[BNRED ? VEC : 1];
+  if constexpr (BNRED) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sg[j] = sx[j] = 0.f; bmean[j] = bn_coef[2 * C + c0 + j]; binv[j] = bn_coef[3 * C + c0 + j]; }
+  }
   for (unsigned pix = blockIdx.x * lanes_r + myr; pix < npix; pix += gridDim.x * lanes_r) {
     const size_t e = (size_t)pix * C + c0;
     const unsigned b = (unsigned)(((unsigned long long)pix * mul_hw) >> 40);
     const f32x4* sp = reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c0);
     const f32x4* dp = reinterpret_cast<const f32x4*>(dpool + (size_t)b * C + c0);
-    Vec16<T> d = ldg16(dout + e), o, xm;
+    Vec16<T> d = ldg16(dout + e), o, xm, yy;
     if (xmask) xm = ldg16(xmask + e);
+    if constexpr (BNRED) yy = ldg16(bn_y + e);
 #pragma unroll
     for (int q4 = 0; q4 < VEC / 4; ++q4) {
       const f32x4 s4 = sp[q4], p4 = dp[q4];
@@ -531,6 +588,25 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
       }
     }
     stg16(dx + e, o);
+    if constexpr (BNRED) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float g = o.get(j);                      // the value as stored: what bn_bwd_apply will read back
+        sg[j] += g; sx[j] += g * (yy.get(j) - bmean[j]) * binv[j];
+      }
+    }
+  }
+  if constexpr (BNRED) {
+    __shared__ float shm[2 * 256 * VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { shm[threadIdx.x * VEC + j] = sg[j]; shm[(256 + threadIdx.x) * VEC + j] = sx[j]; }
+    __syncthreads();
+    for (int o2 = threadIdx.x; o2 < 3 * C; o2 += 256) {
+      const int k = o2 / C, c = o2 - k * C, v = c / VEC, j = c - v * VEC;
+      float t = 0.f;
+      if (k < 2) for (int r = 0; r < lanes_r; ++r) t += shm[(k * 256 + r * cv + v) * VEC + j];
+      bn_slab[((size_t)blockIdx.x * 3 + k) * C + c] = t;
+    }
   }
 }
 
@@ -742,6 +818,27 @@ int vqa_bn_apply(int dtype, const void* y, const float* coef, const void* res, c
 #undef BN_APPLY
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
+// rows of one sample a workgroup of vqa_bn_apply_pool owns (14 passes of the workgroup) and the resulting chunks per sample
+static inline int pool_rpc(int C, int VEC) { return (256 / (C / VEC)) * 14; }
+int vqa_bn_apply_pool_chunks(int dtype, int HW, int C) {
+  const int VEC = dtype ? 8 : 4;
+  if (C % VEC || C / VEC > 256 || 256 % (C / VEC) || HW <= 0) return 0;
+  return (HW + pool_rpc(C, VEC) - 1) / pool_rpc(C, VEC);
+}
+// bn_apply of a stage's last block + the SE pooling sums: part [B][vqa_bn_apply_pool_chunks][C] floats (vqa_se_fwd folds them)
+int vqa_bn_apply_pool(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, void* out, int B, int HW, int C,
+                      int relu, float* part, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  const int chunks = vqa_bn_apply_pool_chunks(dtype, HW, C);
+  if (!y || !coef || !out || !part || B <= 0 || chunks <= 0 || B > 65535) return VQA_EARG;
+  const int rpc = pool_rpc(C, VEC);
+#define BN_APPLYP(TT, R) hipLaunchKernelGGL((bn_apply_pool_kernel<TT, R>), dim3(chunks, B), dim3(256), 0, st, (const TT*)y, coef, (const TT*)res, rcoef, (TT*)out, HW, C, relu, rpc, part)
+  const int mode = !res ? 0 : (rcoef ? 2 : 1);
+  if (dtype) { if (mode == 0) BN_APPLYP(bf16_t, 0); else if (mode == 1) BN_APPLYP(bf16_t, 1); else BN_APPLYP(bf16_t, 2); }
+  else { if (mode == 0) BN_APPLYP(float, 0); else if (mode == 1) BN_APPLYP(float, 1); else BN_APPLYP(float, 2); }
+#undef BN_APPLYP
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
 int vqa_bn_bwd_blocks(long long rows) { long long g = (rows + 63) / 64; return (int)(g > 768 ? 768 : (g < 1 ? 1 : g)); }
 // slab: [vqa_bn_bwd_blocks(rows)][3][C] floats
 int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const void* y, const float* coef, const void* y2, const float* coef2,
@@ -809,31 +906,46 @@ int vqa_stem_bwd_apply(int dtype, const void* dpool, const uint8_t* idx, const v
 }
 
 int vqa_se_fwd(int dtype, const void* x, const float* w1, const float* w2, float* pooled, float* hidden, float* scale, void* out,
-               int B, int HW, int C, int Cr, hipStream_t st) {
+               int B, int HW, int C, int Cr, const float* pool_part, int pool_chunks, hipStream_t st) {
   const int VEC = dtype ? 8 : 4;
   if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  if (pool_part && pool_chunks != vqa_bn_apply_pool_chunks(dtype, HW, C)) return VQA_EARG;
   const size_t shm = ((size_t)256 * VEC + C + Cr) * 4;
-  DT(hipLaunchKernelGGL(se_pool_fc_kernel<float>, dim3(B), dim3(256), shm, st, (const float*)x, w1, w2, pooled, hidden, scale, HW, C, Cr),
-     hipLaunchKernelGGL(se_pool_fc_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)x, w1, w2, pooled, hidden, scale, HW, C, Cr));
+  DT(hipLaunchKernelGGL(se_pool_fc_kernel<float>, dim3(B), dim3(256), shm, st, (const float*)x, w1, w2, pooled, hidden, scale, HW, C, Cr, pool_part, pool_chunks),
+     hipLaunchKernelGGL(se_pool_fc_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)x, w1, w2, pooled, hidden, scale, HW, C, Cr, pool_part, pool_chunks));
   const size_t npix = (size_t)B * HW;
   if (npix >= (1ull << 28)) return VQA_EARG;
   DT(hipLaunchKernelGGL(scale_kernel<float>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const float*)x, scale, (const float*)nullptr, (float*)out, (unsigned)npix, C, magic40(HW)),
      hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const bf16_t*)x, scale, (const float*)nullptr, (bf16_t*)out, (unsigned)npix, C, magic40(HW)));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
+// rows of the BatchNorm-backward slab vqa_se_bwd fills when bn_slab is given (= workgroups of its apply pass)
+int vqa_se_bwd_blocks(int dtype, int B, int HW, int C) {
+  const int VEC = dtype ? 8 : 4;
+  if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return 0;
+  return px_grid((size_t)B * HW, C, VEC);
+}
 // scratch: dz2[B*C] | dh[B*Cr] | dpool[B*C] floats
+// bn_y / bn_coef / bn_slab (all or none): dx is the gradient entering the BatchNorm whose conv output is bn_y (the last block's bn2,
+// mask_out = 1): its backward column sums go to bn_slab[vqa_se_bwd_blocks][3][C] and vqa_bn_bwd_reduce is skipped by the caller.
 int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, const float* w2, const float* pooled, const float* hidden,
-               const float* scale, float* scratch, void* dx, float* dw1, float* dw2, int B, int HW, int C, int Cr, int mask_out, hipStream_t st) {
+               const float* scale, float* scratch, void* dx, float* dw1, float* dw2, int B, int HW, int C, int Cr, int mask_out,
+               const void* bn_y, const float* bn_coef, float* bn_slab, hipStream_t st) {
   const int VEC = dtype ? 8 : 4;
   if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  if ((bn_slab != nullptr) != (bn_y != nullptr) || (bn_slab != nullptr) != (bn_coef != nullptr)) return VQA_EARG;
   float* dz2 = scratch; float* dh = dz2 + (size_t)B * C; float* dpool = dh + (size_t)B * Cr;
   const size_t shm = ((size_t)256 * VEC + C + Cr) * 4;
   DT(hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, dim3(B), dim3(256), shm, st, (const float*)dout, (const float*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr),
      hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr));
   const size_t npix = (size_t)B * HW;
   if (npix >= (1ull << 28)) return VQA_EARG;
-  DT(hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const float*)dout, scale, dpool, (float*)dx, (unsigned)npix, HW, C, magic40(HW), mask_out ? (const float*)x : nullptr),
-     hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(px_grid(npix, C, VEC)), dim3(256), 0, st, (const bf16_t*)dout, scale, dpool, (bf16_t*)dx, (unsigned)npix, HW, C, magic40(HW), mask_out ? (const bf16_t*)x : nullptr));
+  const int ag = px_grid(npix, C, VEC);
+#define SE_APPLY(TT, R) hipLaunchKernelGGL((se_bwd_apply_kernel<TT, R>), dim3(ag), dim3(256), 0, st, (const TT*)dout, scale, dpool, (TT*)dx, (unsigned)npix, HW, C, \
+    magic40(HW), mask_out ? (const TT*)x : nullptr, (const TT*)bn_y, bn_coef, bn_slab)
+  if (dtype) { if (bn_slab) SE_APPLY(bf16_t, true); else SE_APPLY(bf16_t, false); }
+  else { if (bn_slab) SE_APPLY(float, true); else SE_APPLY(float, false); }
+#undef SE_APPLY
   hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 7) / 8), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }

@@ -52,6 +52,8 @@ class HipEngine:
         self.bias_offpath = False
         self.use_c64_fwd = False                  # 4-wave stage-1 patch kernel for forward / data gradient (superseded by the 8-wave one)
         self.use_c64p = True                      # 8-wave weights-resident stage-1 conv kernel
+        self.fuse_se_pool = True                  # SE global-average-pool sums leave the last block's bn_apply (one read of the stage output less)
+        self.fuse_se_bnred = True                 # the last block's bn2-backward column sums leave the SE backward apply pass (ditto)
         self._stem_fcoef = None
         self.fold_eval = True                     # inference (eval, no tape): Conv+BN folded, BN never runs as its own pass
         self._fold = None                         # (key, table, nd, blocks, wbuf, bbuf, views)
@@ -468,11 +470,17 @@ class HipEngine:
                 y2, st2, mt2, g2, _, _ = self._conv(a1, B, Ho, Wo, Cout, p + ".conv2.weight", Cout, 3, 1, 1, training)
                 c2 = self._bn_coef(p + ".bn2", st2, mt2, Cout, M, training)
                 rec = dict(p=p, x=x, y1=y1, c1=c1, a1=a1, y2=y2, c2=c2, g1=g1, g2=g2, M=M, Cin=Cin, Cout=Cout)
+                # the stage's last block hands the SE pooling sums over (its output is the SE input)
+                pool_here = (b == 1 and self.fuse_se_pool and (f"image_encoder.stage{s}.attention.se.fc1.weight") in self.E
+                             and K.L.count("vqa_bn_apply_pool_chunks", dt(T), Ho * Wo, Cout) > 0 and B <= 65535)
                 if (p + ".downsample.0.weight") in self.E:
                     yd, std, mtd, gd, _, _ = self._conv(x, B, H, W, Cin, p + ".downsample.0.weight", Cout, 1, stride, 0, training)
                     cd = self._bn_coef(p + ".downsample.1", std, mtd, Cout, M, training)
                     out = K.bn_apply(y2, c2, Cout, relu=True, res=yd, rcoef=cd)
                     rec.update(yd=yd, cd=cd, gd=gd)
+                elif pool_here:
+                    out, pool_part, pool_chunks = K.bn_apply_pool(y2, c2, Cout, True, B, Ho * Wo, res=x)
+                    srec["pool"] = (pool_part, pool_chunks)
                 else:
                     out = K.bn_apply(y2, c2, Cout, relu=True, res=x)
                 rec["out"] = out
@@ -485,8 +493,9 @@ class HipEngine:
                 hidden = torch.empty((B, Cr), device=dev, dtype=torch.float32)
                 scale = torch.empty((B, C), device=dev, dtype=torch.float32)
                 out = torch.empty_like(x)
+                pool_part, pool_chunks = srec.pop("pool", (None, 0))
                 call("vqa_se_fwd", dt(T), ptr(x), ptr(self.P(ap + ".se.fc1.weight")), ptr(self.P(ap + ".se.fc2.weight")),
-                     ptr(pooled), ptr(hidden), ptr(scale), ptr(out), B, H * W, C, Cr)
+                     ptr(pooled), ptr(hidden), ptr(scale), ptr(out), B, H * W, C, Cr, ptr(pool_part), pool_chunks)
                 srec["se"] = dict(x=x, pooled=pooled, hidden=hidden, scale=scale, Cr=Cr, HW=H * W, C=C)
                 x = out
             if (ap + ".spatial.conv.weight") in self.E:
@@ -763,15 +772,24 @@ class HipEngine:
                 r = srec["se"]
                 scratch = torch.empty((B * (2 * r["C"] + r["Cr"]),), device=dxc.device, dtype=torch.float32)
                 dxn = torch.empty_like(r["x"])
+                # dxn is the gradient entering the last block's bn2: its BatchNorm-backward column sums leave the same pass
+                lastb = srec["blocks"][-1]
+                se_pre = None
+                if self.fuse_se_bnred and "yd" not in lastb:
+                    nblk = K.L.count("vqa_se_bwd_blocks", dt(T), B, r["HW"], r["C"])
+                    if nblk > 0:
+                        se_pre = (torch.empty((nblk, 3, r["C"]), device=dxc.device, dtype=torch.float32), nblk)
                 call("vqa_se_bwd", dt(T), ptr(dxc), ptr(r["x"]), ptr(self.P(ap + ".se.fc1.weight")), ptr(self.P(ap + ".se.fc2.weight")),
                      ptr(r["pooled"]), ptr(r["hidden"]), ptr(r["scale"]), ptr(scratch), ptr(dxn),
-                     ptr(self._gslice(G, ap + ".se.fc1.weight")), ptr(self._gslice(G, ap + ".se.fc2.weight")), B, r["HW"], r["C"], r["Cr"], 1)
+                     ptr(self._gslice(G, ap + ".se.fc1.weight")), ptr(self._gslice(G, ap + ".se.fc2.weight")), B, r["HW"], r["C"], r["Cr"], 1,
+                     ptr(lastb["y2"]) if se_pre else None, ptr(lastb["c2"]) if se_pre else None, ptr(se_pre[0]) if se_pre else None)
                 dxc = dxn
                 masked = True                 # the SE input IS the last block's post-ReLU output: its mask was applied on the way out
             else:
                 masked = False
+                se_pre = None
             nb = len(srec["blocks"])
-            pre = None           # BatchNorm-backward sums of the next block's bn2, already reduced by the epilogue that produced dxc
+            pre = se_pre         # BatchNorm-backward sums of the next block's bn2, already reduced by the pass that produced dxc
             for bi in range(nb - 1, -1, -1):
                 rec = srec["blocks"][bi]
                 # the gradient handed to the previous block of the stage is masked by THAT block's ReLU in this block's epilogue,

@@ -29,14 +29,15 @@ HBM_BYTES = {
     # dout, y (+ activation, + shortcut y); backward apply reads dout, y (+ activation) and writes dy (+ shortcut: y2 in, dy2 out)
     "vqa_bn_stats_finalize": ("bn", lambda a: a[1] * a[2] * 2 * 4 + a[2] * 4 * 8),
     "vqa_bn_apply": ("bn", lambda a: a[6] * _ES(a[0]) * (2 + _P(a[3]))),
+    "vqa_bn_apply_pool": ("bn", lambda a: a[6] * a[7] * a[8] * _ES(a[0]) * (2 + _P(a[3]))),
     "vqa_bn_bwd_reduce": ("bn", lambda a: a[8] * a[9] * _ES(a[0]) * (2 + _P(a[2]) + _P(a[5]))),
     "vqa_bn_bwd_finalize": ("bn", lambda a: a[1] * a[2] * 3 * 4),
     "vqa_bn_bwd_apply": ("bn", lambda a: a[9] * _ES(a[0]) * (3 + _P(a[2]) + 2 * _P(a[6]))),
     "vqa_stem_pool_fwd": ("stem_pool", lambda a: a[5] * a[6] * a[7] * a[8] * _ES(a[0])
                           + a[5] * ((a[6] - 1) // 2 + 1) * ((a[7] - 1) // 2 + 1) * a[8] * (_ES(a[0]) + 1)),
     # SE / spatial attention (A4, A5): pool read + scale read + write forward; dout, x in and dx out backward
-    "vqa_se_fwd": ("se_spatial", lambda a: 3 * a[8] * a[9] * a[10] * _ES(a[0])),
-    "vqa_se_bwd": ("se_spatial", lambda a: 3 * a[12] * a[13] * a[14] * _ES(a[0])),
+    "vqa_se_fwd": ("se_spatial", lambda a: (2 if a[12] else 3) * a[8] * a[9] * a[10] * _ES(a[0])),      # pool sums handed over: no pool read
+    "vqa_se_bwd": ("se_spatial", lambda a: (3 + _P(a[17])) * a[12] * a[13] * a[14] * _ES(a[0])),        # + the BatchNorm operand when fused
     "vqa_spatial_fwd": ("se_spatial", lambda a: 3 * a[7] * a[8] * a[9] * a[10] * _ES(a[0])),
     "vqa_spatial_bwd": ("se_spatial", lambda a: 3 * a[10] * a[11] * a[12] * a[13] * _ES(a[0])),
     # token side: LayerNorm, bias / activation backward, pools, gate, adds, embedding, attention (its FLOPs are tiny: latency class)
@@ -363,6 +364,15 @@ def bn_apply(y, coef, C, relu, res=None, rcoef=None):
     out = torch.empty_like(y)
     call("vqa_bn_apply", dt(y), ptr(y), ptr(coef), ptr(res), ptr(rcoef), ptr(out), y.numel(), C, int(relu))
     return out
+
+
+def bn_apply_pool(y, coef, C, relu, B, HW, res=None, rcoef=None):
+    """bn_apply of a stage's last block that also leaves the SE pooling sums: returns (out, part [B][chunks][C], chunks)."""
+    out = torch.empty_like(y)
+    chunks = L.count("vqa_bn_apply_pool_chunks", dt(y), HW, C)
+    part = torch.empty((B, chunks, C), device=y.device, dtype=torch.float32)
+    call("vqa_bn_apply_pool", dt(y), ptr(y), ptr(coef), ptr(res), ptr(rcoef), ptr(out), B, HW, C, int(relu), ptr(part))
+    return out, part, chunks
 
 
 def bn_bwd(dout, outact, y, coef, gamma, C, training, dgamma, dbeta, y2=None, coef2=None, gamma2=None, dgamma2=None, dbeta2=None,
