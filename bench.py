@@ -28,14 +28,7 @@ import os
 import sys
 import time
 
-# One process drives one GPU with FOUR of its own HIP streams (main, text-encoder side stream, weight-gradient side stream,
-# communication stream) next to the streams RCCL / torch.distributed create.  The HIP runtime multiplexes streams onto 4 hardware
-# queues by default: measured on MI355X, a live RCCL communicator then pushes the side streams onto the main stream's queue and
-# the train step slows from 13.1 to 13.9 ms WITHOUT a single collective being issued (tools/pg_overhead.py); 8 queues restore it.
-# Must be set before the HIP runtime initialises (importing the product package does the same, see its __init__).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-import torch  # noqa: E402
+import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:

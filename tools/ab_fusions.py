@@ -1,0 +1,36 @@
+"""A/B of the engine's schedule switches on one box: python tools/ab_fusions.py  (B=512 bf16, 30 timed steps each, repeated twice)."""
+import importlib, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch
+import bench
+pkg = importlib.import_module("visual-question-answering-vqa-system_amd")
+M = pkg.load_dropin()
+data = bench.synth_batch(512, torch.device("cuda", 0), 1234)
+CASES = [("default", {}), ("no se_pool", dict(fuse_se_pool=False)), ("no se_bnred", dict(fuse_se_bnred=False)),
+         ("neither", dict(fuse_se_pool=False, fuse_se_bnred=False))]
+NC = int(os.environ.get("AB_CASES", "4"))
+for rep in range(int(os.environ.get("AB_REPS", "2"))):
+    for tag, kw in CASES[:NC]:
+        model = M.VQAModel(compute_dtype="bf16", seed=1234).to("cuda").train()
+        tr = pkg.trainer.HipTrainer(model)
+        for k, v in kw.items():
+            setattr(tr.engine, k, v)
+        for _ in range(8):
+            tr.step(*data)
+        torch.cuda.synchronize()
+        st0 = torch.cuda.memory_stats()
+        t0 = time.perf_counter()
+        host = []
+        for _ in range(int(os.environ.get('AB_STEPS', '30'))):
+            h0 = time.perf_counter()
+            tr.step(*data)
+            host.append(time.perf_counter() - h0)
+        torch.cuda.synchronize()
+        st1 = torch.cuda.memory_stats()
+        host.sort()
+        print(f"{tag:14s} {(time.perf_counter() - t0) / 30 * 1e3:7.3f} ms/step   host median {host[len(host)//2]*1e3:6.2f} max {host[-1]*1e3:6.2f}  "
+              f"device allocs +{st1['num_device_alloc'] - st0['num_device_alloc']} frees +{st1['num_device_free'] - st0['num_device_free']} "
+              f"retries +{st1['num_alloc_retries'] - st0['num_alloc_retries']} reserved {st1['reserved_bytes.all.current'] / 2**30:.1f} GiB", flush=True)
+        del tr, model
+        torch.cuda.empty_cache()

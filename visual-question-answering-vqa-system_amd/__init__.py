@@ -3,15 +3,7 @@
 Import with importlib (the directory name is not a Python identifier):
     pkg = importlib.import_module("visual-question-answering-vqa-system_amd")
 """
-import os as _os
-
-# The engine runs a train step on three HIP streams (+ the reducer's communication stream, + RCCL's own).  The HIP runtime maps
-# streams onto 4 hardware queues unless told otherwise; with a live RCCL communicator the side streams then share the main
-# stream's queue and the step loses ~6 % (measured, tools/pg_overhead.py).  Effective only if the HIP runtime has not been
-# initialised yet in this process (set GPU_MAX_HW_QUEUES in the launcher's environment otherwise -- INTEGRATION.md).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-from . import _lib, kernels  # noqa: F401,E402
+from . import _lib, kernels  # noqa: F401
 from . import layout, engine, trainer, flops  # noqa: F401,E402
 
 

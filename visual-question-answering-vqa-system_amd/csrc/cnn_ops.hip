@@ -569,6 +569,7 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { sg[j] = sx[j] = 0.f; bmean[j] = bn_coef[2 * C + c0 + j]; binv[j] = bn_coef[3 * C + c0 + j]; }
   }
+#pragma unroll 2
   for (unsigned pix = blockIdx.x * lanes_r + myr; pix < npix; pix += gridDim.x * lanes_r) {
     const size_t e = (size_t)pix * C + c0;
     const unsigned b = (unsigned)(((unsigned long long)pix * mul_hw) >> 40);
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
       const f32x4 s4 = sp[q4], p4 = dp[q4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float v = d.get(q4 * 4 + j) * s4[j] + p4[j] * inv;
+        float v = fmaf(d.get(q4 * 4 + j), s4[j], p4[j] * inv);     // explicit: both instantiations round identically
         if (xmask && !(xm.get(q4 * 4 + j) > 0.f)) v = 0.f;
         o.set(q4 * 4 + j, v);
       }
@@ -923,7 +924,8 @@ int vqa_se_fwd(int dtype, const void* x, const float* w1, const float* w2, float
 int vqa_se_bwd_blocks(int dtype, int B, int HW, int C) {
   const int VEC = dtype ? 8 : 4;
   if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return 0;
-  return px_grid((size_t)B * HW, C, VEC);
+  const int g = px_grid((size_t)B * HW, C, VEC);
+  return g > 2048 ? 2048 : g;          // slab rows vqa_bn_bwd_finalize folds (it is sized for <= ~1k rows: 16384 rows cost it +90 us)
 }
 // scratch: dz2[B*C] | dh[B*Cr] | dpool[B*C] floats
 // bn_y / bn_coef / bn_slab (all or none): dx is the gradient entering the BatchNorm whose conv output is bn_y (the last block's bn2,
@@ -940,7 +942,7 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
      hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr));
   const size_t npix = (size_t)B * HW;
   if (npix >= (1ull << 28)) return VQA_EARG;
-  const int ag = px_grid(npix, C, VEC);
+  const int ag = bn_slab ? vqa_se_bwd_blocks(dtype, B, HW, C) : px_grid(npix, C, VEC);
 #define SE_APPLY(TT, R) hipLaunchKernelGGL((se_bwd_apply_kernel<TT, R>), dim3(ag), dim3(256), 0, st, (const TT*)dout, scale, dpool, (TT*)dx, (unsigned)npix, HW, C, \
     magic40(HW), mask_out ? (const TT*)x : nullptr, (const TT*)bn_y, bn_coef, bn_slab)
   if (dtype) { if (bn_slab) SE_APPLY(bf16_t, true); else SE_APPLY(bf16_t, false); }

@@ -19,6 +19,45 @@ from . import layout as LY
 from ._lib import call, dt, ptr
 
 
+def _streams_overlap(a: "torch.cuda.Stream", b: "torch.cuda.Stream", cycles: int = 1_500_000) -> bool:
+    """True when work on `b` really runs while `a` is busy.  The HIP runtime multiplexes streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default, least-used queue first): two streams that landed on the same queue execute strictly one
+    after the other.  Probe: a ~1 ms spin kernel on a, a tiny one on b; if b's finishes while a's is still running, they overlap."""
+    ea, eb = torch.cuda.Event(), torch.cuda.Event()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(cycles)
+        ea.record()
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(1000)
+        eb.record()
+    eb.synchronize()
+    ok = not ea.query()
+    ea.synchronize()
+    return ok
+
+
+def pick_concurrent_streams(device, n: int, avoid=(), tries: int = 12):
+    """n new streams that overlap with the current stream, with `avoid` and with each other (measured, see _streams_overlap).
+    Measured on MI355X: a second engine in one process, or an engine built after an RCCL communicator, gets side streams from
+    torch's pool that SHARE the main stream's hardware queue -- the weight-gradient stream then serialises with the data-gradient
+    chain and a 13.2 ms train step takes 19 ms.  Falls back to plain new streams when no candidate passes."""
+    main = torch.cuda.current_stream(device)
+    if torch.cuda.is_current_stream_capturing():
+        return tuple(torch.cuda.Stream(device=device) for _ in range(n))
+    chosen, spare = [], []
+    for _ in range(tries):
+        if len(chosen) == n:
+            break
+        c = torch.cuda.Stream(device=device)
+        if all(_streams_overlap(o, c) for o in [main, *avoid, *chosen]):
+            chosen.append(c)
+        else:
+            spare.append(c)
+    while len(chosen) < n:
+        chosen.append(spare.pop(0) if spare else torch.cuda.Stream(device=device))
+    return tuple(chosen)
+
+
 class HipEngine:
     def __init__(self, cfg: dict, entries: List[LY.Entry], flat: torch.Tensor, buffers: Dict[str, torch.Tensor],
                  compute_dtype: torch.dtype):
@@ -44,6 +83,7 @@ class HipEngine:
         # schedule switches: plain attributes (tools/ flip them for A/B measurements); the product never reads the environment
         self.defer_tail = True
         self._deferred = []
+        self._keep = []
         self._wgq = []
         self.group_wgrad = True
         self._foldq = []                          # deferred folds of the LayerNorm / bias parameter gradients (K.fold_group at segment end)
@@ -58,9 +98,9 @@ class HipEngine:
         self.fold_eval = True                     # inference (eval, no tape): Conv+BN folded, BN never runs as its own pass
         self._fold = None                         # (key, table, nd, blocks, wbuf, bbuf, views)
         self.stem_w = None
-        # the text encoder (many tiny, latency-bound launches) runs on its own stream beside the CNN, forward and backward
-        self.side = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
-        self.side2 = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None   # CNN weight gradients (off the critical path)
+        # the text encoder (many tiny, latency-bound launches) runs on its own stream beside the CNN, forward and backward;
+        # the CNN weight gradients run on a second side stream (off the critical path)
+        self.side, self.side2 = pick_concurrent_streams(flat.device, 2) if flat.is_cuda else (None, None)
         self.two_streams = True
         self.wgrad_stream = True
         # test hook (tests/test_gpu_insitu.py): a dict here receives, per residual block, the intermediate gradients of its backward
@@ -358,8 +398,13 @@ class HipEngine:
         cur = torch.cuda.current_stream()
         ev = torch.cuda.Event(); ev.record(cur)
         self.side2.wait_event(ev)
-        for t in tensors:
-            t.record_stream(self.side2)
+        # `tensors` were allocated on the current stream and are read on the side stream: they are kept alive until backward has
+        # joined the side stream again (_keep, released at the end of backward) instead of record_stream()'ed.  record_stream
+        # defers a block's reuse until an event polled at some LATER allocation completes -- with the host a step ahead of the GPU
+        # that made the caching allocator's alloc / free sequence timing-dependent: it never reached a steady state (4 hipMalloc per
+        # step after 40 steps, 25 ms host stalls, reserved memory creeping up by ~3 MB per step).  Held references free in a fixed
+        # order, so every step replays the same allocation sequence.
+        self._keep.extend(tensors)
         with torch.cuda.stream(self.side2):
             fn()
 
@@ -672,6 +717,7 @@ class HipEngine:
         training = tape["training"]
         B = tape["B"]
         self._deferred = []                       # (a backward that raised must not leak its held-back launches into this one)
+        self._keep = []                           # tensors read on a side stream: released after the join at the end of backward
         self._wgq = []
         self._foldq = []
         self._foldq2 = []
@@ -741,7 +787,7 @@ class HipEngine:
         if use_side:
             evf = torch.cuda.Event(); evf.record(main)
             self.side.wait_event(evf)
-            denc.record_stream(self.side)                 # allocated on main, consumed on the side stream
+            self._keep.append(denc)                       # allocated on main, consumed on the side stream: alive until the join below
         with torch.cuda.stream(self.side if use_side else main):
             fn = tape["final_norm"]
             dx = self._ln_bwd(denc, fn["x"], "text_encoder.final_norm", fn["st"], G)
@@ -809,6 +855,7 @@ class HipEngine:
         self._join_off_path()
         if use_side:
             main.wait_event(ev_tb)
+        self._keep = []                           # main is now ordered after every side-stream reader: plain frees are safe
 
     def _flush_deferred_and_report(self, seg):
         had_deferred = bool(self._deferred)

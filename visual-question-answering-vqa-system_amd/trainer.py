@@ -36,7 +36,7 @@ class GradBucketReducer:
     """Sum-all-reduce of contiguous gradient buckets, issued group by group while backward is still running.
     Device-agnostic (CUDA tensors: side stream + events, RCCL; CPU tensors: gloo) so the N>1 logic is testable on CPU."""
 
-    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, overlap=True, force=False):
+    def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, overlap=True, force=False, avoid_streams=()):
         """force: run the whole bucket choreography (communication stream, events, async all-reduce per bucket, waits) even in a
         world of ONE rank -- a single-rank RCCL group executes the same code path an 8-GPU job does, so the one-GPU test box can
         run it for real (tests/test_gpu_nccl_world1.py, bench.py --force-reducer); needs an initialised process group."""
@@ -66,7 +66,10 @@ class GradBucketReducer:
             raise RuntimeError("GradBucketReducer(force=True) needs an initialised torch.distributed process group")
         self.active = self.world > 1 or force
         self.overlap = overlap and flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream() if (self.active and self.overlap) else None
+        self.comm_stream = None
+        if self.active and self.overlap:        # a stream that does not share a hardware queue with the compute streams (engine.py)
+            from .engine import pick_concurrent_streams
+            self.comm_stream = pick_concurrent_streams(flat_grad.device, 1, avoid=avoid_streams)[0]
         self._works: List = []
         self.issued: List[str] = []
         self.bytes_reduced = 0
@@ -155,7 +158,8 @@ class HipTrainer:
         self.bad_targets = torch.zeros(2, device=flat.device, dtype=torch.int32)   # {rows out of range, steps skipped} since the last check()
         self.t = 0
         self.buckets = LY.bucket_ranges(model._entries)
-        self.reducer = GradBucketReducer(self.G, self.buckets, process_group, overlap, force=force_reducer)
+        self.reducer = GradBucketReducer(self.G, self.buckets, process_group, overlap, force=force_reducer,
+                                         avoid_streams=[st for st in (self.engine.side, self.engine.side2) if st is not None])
         self.world = self.reducer.world
 
     def step(self, images, token_ids, attention_mask, targets, metrics=None):
