@@ -34,6 +34,7 @@ int vqa_igemm_variant(int dtype, int loader, int M, int N, int Kw, int B, int H,
 int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, const float* bias, const void* addend,
               const void* addmask, const void* outmask /* out *= (outmask > 0), applied last */, float* stats, int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
+              int stats_mode /* 0: stats = float slab [mtiles][2][N]; 1: stats = fixed-point accumulator (see vqa_bn_apply_acc) */,
               hipStream_t stream);
 /* dw[N][Kw] += dy[M][N]^T * gather(x)[M][Kw], split over the M pixels.
  * With a workspace (`ws`, caller-owned scratch of >= the ws_floats vqa_wgrad_plan reports; contents undefined afterwards) every
@@ -61,7 +62,8 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
 /* same conv (forward, or data gradient with the flipped pack) without epilogue inputs: 8-wave persistent kernel, 8 output rows per
  * block, input patches by LDS-DMA, weights in registers; stats [vqa_conv3x3_c64p_blocks][2][64] or NULL.  H % 8 == 0, W % 8 == 0. */
 int vqa_conv3x3_c64p_blocks(int B, int H, int W);
-int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, hipStream_t stream);
+int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W,
+                     int stats_mode /* 1: stats is the fixed-point accumulator u64 [2*64 + 1] of vqa_bn_apply_acc */, hipStream_t stream);
 /* stage-2 weight gradient (3x3 / 1 / pad 1, 128 -> 128 channels, 28 x 28 maps, bf16; models/cnn_backbone.py:182-187 backward): 8-wave
    LDS-DMA kernel + fixed-order slab reduce.  vqa_wgrad3x3_c128_blocks: slabs of 128*576 floats the workspace must hold, 0 = shape not
    supported (the caller uses vqa_wgrad). */
@@ -110,10 +112,28 @@ int vqa_bn_apply(int dtype, const void* y, const float* coef, const void* res, c
 int vqa_bn_apply_pool_chunks(int dtype, int HW, int C);
 int vqa_bn_apply_pool(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, void* out, int B, int HW, int C,
                       int relu, float* part, hipStream_t stream);
+/* Fixed-point statistics (round 3).  A producer launched with stats_mode = 1 (vqa_igemm, vqa_conv3x3_c64p) adds its per-workgroup
+   fp32 partial sums  sum y | sum y^2  to acc[vqa_bn_acc_words(2, C)] (unsigned 64-bit, scaled by 2^24, caller-zeroed; the last used
+   word counts partials that were non-finite / out of range -> NaN statistics) with integer atomics: order-independent, hence bit-reproducible, and complete
+   when the producer ends.  vqa_bn_apply_acc then does finalize (fp64, nn.BatchNorm2d training formulas, running-statistics update,
+   coef_out [4][C] = scale | shift | mean | invstd for the backward) + apply (+ res | + BatchNorm(res) from racc, + ReLU) in ONE
+   launch -- the finalize launches between conv and apply are gone.  pool_part != NULL: also the SE pooling sums (vqa_bn_apply_pool).
+   Backward: vqa_bn_bwd_reduce(acc_mode = 1) / vqa_se_bwd(bn_acc_mode = 1) add  sum g | sum g*xhat | sum g*xhat2  (scaled 2^40) to
+   facc[vqa_bn_acc_words(3, C)]; vqa_bn_bwd_apply_acc derives the apply coefficients in its prologue and adds d gamma / d beta. */
+int vqa_bn_acc_words(int K, int C);   /* 64-bit words of an accumulator for K sums x C channels: R = clamp(512/C, 1, 8) replicas
+                                         (same-address atomics are serialised, ~21 ns each) + the flag word; K = 2 forward, 3 backward */
+int vqa_bn_apply_acc(int dtype, const void* y, const unsigned long long* acc, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, long long* num_batches_tracked, float* coef_out, const void* res,
+                     const unsigned long long* racc, const float* rgamma, const float* rbeta, float* rrunning_mean, float* rrunning_var,
+                     long long* rnum_batches_tracked, float* rcoef_out, void* out, int B, int HW, int C, int relu, double count,
+                     float momentum, float eps, float* pool_part, hipStream_t stream);
 int vqa_bn_bwd_blocks(long long rows);
 int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const void* y, const float* coef, const void* y2,
-                      const float* coef2, float* slab /* [blocks][3][C] */, long long rows, int C, int self_mask /* mask = relu(bn(y))>0 from y */,
-                      hipStream_t stream);
+                      const float* coef2, float* slab /* [blocks][3][C], or the u64 accumulator [3*C + 1] when acc_mode = 1 */, long long rows,
+                      int C, int self_mask /* mask = relu(bn(y))>0 from y */, int acc_mode, hipStream_t stream);
+int vqa_bn_bwd_apply_acc(int dtype, const void* dout, const void* outact, const void* y, const unsigned long long* facc, const float* gamma,
+                         const float* coef, float* dgamma, float* dbeta, void* dy, const void* y2, const float* gamma2, const float* coef2,
+                         float* dgamma2, float* dbeta2, void* dy2, long long numel, int C, double count, int self_mask, hipStream_t stream);
 int vqa_bn_bwd_finalize(const float* slab, int nblk, int C, int which, double count, const float* gamma, const float* coef,
                         int training, float* dgamma, float* dbeta, float* bcoef /* 3*C */, hipStream_t stream);
 int vqa_bn_bwd_apply(int dtype, const void* dout, const void* outact, const void* y, const float* bcoef, void* dy,
@@ -138,7 +158,8 @@ int vqa_se_bwd_blocks(int dtype, int B, int HW, int C);
 int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, const float* w2, const float* pooled,
                const float* hidden, const float* scale, float* scratch /* B*(2C+Cr) */, void* dx, float* dw1, float* dw2,
                int B, int HW, int C, int Cr, int mask_out /* dx *= (x > 0): x is a post-ReLU activation */,
-               const void* bn_y, const float* bn_coef, float* bn_slab, hipStream_t stream);
+               const void* bn_y, const float* bn_coef, float* bn_slab /* or the u64 accumulator when bn_acc_mode = 1 */, int bn_acc_mode,
+               hipStream_t stream);
 /* ---- SpatialAttention.forward (models/attention_modules.py:223-243) and its backward ----------------------------- */
 int vqa_spatial_fwd(int dtype, const void* x, const float* w /* (1,2,7,7) */, float* pooled2, int* argmax, float* amap,
                     void* out, int B, int H, int W, int C, hipStream_t stream);

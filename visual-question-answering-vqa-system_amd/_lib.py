@@ -19,7 +19,7 @@ P, I, F, D, LL, ULL = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong, 
 SIGNATURES = {
     "vqa_igemm_mtiles": [I, I, I],
     "vqa_igemm_variant": [I] * 15,
-    "vqa_igemm": [I, I, P, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, P],
+    "vqa_igemm": [I, I, P, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, I, P],
     "vqa_wgrad_plan": [I] * 11 + [P, P, P, P, P],
     "vqa_wgrad": [I, I, P, P, P] + [I] * 13 + [P, LL, P],
     "vqa_pack_rows": [I, P, P, I, I, I, P],
@@ -29,7 +29,7 @@ SIGNATURES = {
     "vqa_conv3x3_c64_blocks": [I, I, I],
     "vqa_conv3x3_c64": [P, P, P, P, P, P, I, I, I, P],
     "vqa_conv3x3_c64p_blocks": [I, I, I],
-    "vqa_conv3x3_c64p": [P, P, P, P, I, I, I, P],
+    "vqa_conv3x3_c64p": [P, P, P, P, I, I, I, I, P],
     "vqa_wgrad3x3_c128_blocks": [I, I, I],
     "vqa_wgrad3x3_c128": [P, P, P, I, I, I, P, LL, P],
     "vqa_wgrad3x3_c64": [P, P, P, I, I, I, P, LL, P],
@@ -50,14 +50,17 @@ SIGNATURES = {
     "vqa_bn_apply_pool": [I, P, P, P, P, P, I, I, I, I, P, P],
     "vqa_se_bwd_blocks": [I, I, I, I],
     "vqa_bn_bwd_blocks": [LL],
-    "vqa_bn_bwd_reduce": [I, P, P, P, P, P, P, P, LL, I, I, P],
+    "vqa_bn_bwd_reduce": [I, P, P, P, P, P, P, P, LL, I, I, I, P],
+    "vqa_bn_acc_words": [I, I],
+    "vqa_bn_apply_acc": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, D, F, F, P, P],
+    "vqa_bn_bwd_apply_acc": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, LL, I, D, I, P],
     "vqa_bn_bwd_finalize": [P, I, I, I, D, P, P, I, P, P, P, P],
     "vqa_bn_bwd_apply": [I, P, P, P, P, P, P, P, P, LL, I, P, P],
     "vqa_stem_pool_fwd": [I, P, P, P, P, I, I, I, I, P],
     "vqa_stem_bwd_reduce": [I, P, P, P, P, P, I, I, I, I, P],
     "vqa_stem_bwd_apply": [I, P, P, P, P, P, P, I, I, I, I, P],
     "vqa_se_fwd": [I, P, P, P, P, P, P, P, I, I, I, I, P, I, P],
-    "vqa_se_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P],
+    "vqa_se_bwd": [I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, P],
     "vqa_spatial_fwd": [I, P, P, P, P, P, P, I, I, I, I, P],
     "vqa_spatial_bwd_scratch": [I, I, I],
     "vqa_spatial_bwd": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
@@ -93,7 +96,7 @@ SIGNATURES = {
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P, P, P],
 }
 _RET_LL = {"vqa_image_resize_ws", "vqa_wgrad_group_ws", "vqa_spatial_bwd_scratch", "vqa_layernorm_bwd_ws", "vqa_bias_act_bwd_ws"}                       # return a size (long long)
-_NO_STATUS = _RET_LL | {"vqa_bn_apply_pool_chunks", "vqa_se_bwd_blocks", "vqa_wgrad3x3_c128_blocks", "vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
+_NO_STATUS = _RET_LL | {"vqa_bn_acc_words", "vqa_bn_apply_pool_chunks", "vqa_se_bwd_blocks", "vqa_wgrad3x3_c128_blocks", "vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks"}   # return a count, not a status
 
 _lib = None
 

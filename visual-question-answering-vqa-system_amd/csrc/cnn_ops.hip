@@ -157,6 +157,89 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const T* __restrict_
   }
 }
 
+// Train-mode BatchNorm whose batch statistics arrive as fixed-point accumulators (common.h acc_add_fixed; filled by the conv
+// kernel's epilogue): every thread finalizes the coefficients of ITS channels in the prologue (fp64, same formulas as
+// bn_finalize_kernel), the first workgroup also publishes coef[4][C] (scale | shift | mean | invstd: the backward reads it) and
+// updates running_mean / running_var / num_batches_tracked (nn.BatchNorm2d defaults).  No finalize launch in between.
+struct BnAcc {
+  const unsigned long long* acc; const float* gamma; const float* beta; float* rm; float* rv; long long* nbt; float* coef;
+};
+// One evaluation per channel and workgroup (the results are shared through LDS), fp64 only for the cancellation-prone
+// var = E[y^2] - mean^2; 1/count arrives precomputed and 1/sqrt is the fp32 hardware instruction -- a first version that divided
+// and took square roots in fp64 in every thread cost 3x the streaming work of the kernel.
+__device__ __forceinline__ void bn_acc_coef(const BnAcc& f, int C, int c, double inv_count, double unbias, float momentum, float eps, bool writer,
+                                            float& sc, float& sh) {
+  const int R = acc_replicas(C);
+  const double s = acc_read_fixed<VQA_ACC_FWD_SHIFT>(f.acc, R, 2, C, 0, c), q = acc_read_fixed<VQA_ACC_FWD_SHIFT>(f.acc, R, 2, C, 1, c);
+  double mean = s * inv_count;
+  double var = q * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  if (f.acc[(size_t)R * 2 * C] != 0) mean = __builtin_nan("");                 // a partial sum left the fixed-point range / was not finite
+  const float invstd = rsqrtf((float)var + eps);
+  sc = f.gamma[c] * invstd; sh = f.beta[c] - (float)mean * sc;
+  if (writer) {
+    f.coef[c] = sc; f.coef[C + c] = sh; f.coef[2 * C + c] = (float)mean; f.coef[3 * C + c] = invstd;
+    if (f.rm) {
+      f.rm[c] = (1.f - momentum) * f.rm[c] + momentum * (float)mean;
+      f.rv[c] = (1.f - momentum) * f.rv[c] + momentum * (float)(var * unbias);
+      if (c == 0 && f.nbt) *f.nbt += 1;
+    }
+  }
+}
+// RES: 0 none, 1 + res, 2 + BatchNorm(res) with its own accumulators.  POOL: grid (chunks, B), SE pooling sums to part (see above).
+template <typename T, int RES, bool POOL>
+__global__ __launch_bounds__(256) void bn_apply_acc_kernel(const T* __restrict__ y, BnAcc f, const T* __restrict__ res, BnAcc fr,
+                                                           T* __restrict__ out, size_t rows, int HW, int C, int relu, int rpc, double inv_count,
+                                                           double unbias, float momentum, float eps, float* __restrict__ part) {
+  constexpr int VEC = Vec16<T>::N;
+  const int cv = C / VEC, lanes_r = 256 / cv;
+  const int c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
+  const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+  extern __shared__ float cf[];                // [2 | 4][C]: scale, shift (, residual scale, shift)
+  for (int c = threadIdx.x; c < C; c += 256) {
+    bn_acc_coef(f, C, c, inv_count, unbias, momentum, eps, writer, cf[c], cf[C + c]);
+    if (RES == 2) bn_acc_coef(fr, C, c, inv_count, unbias, momentum, eps, writer, cf[2 * C + c], cf[3 * C + c]);
+  }
+  __syncthreads();
+  float sc[VEC], sh[VEC], rs[RES == 2 ? VEC : 1], rh[RES == 2 ? VEC : 1], acc[POOL ? VEC : 1];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = cf[c0 + j]; sh[j] = cf[C + c0 + j];
+    if (RES == 2) { rs[j] = cf[2 * C + c0 + j]; rh[j] = cf[3 * C + c0 + j]; }
+    if (POOL) acc[j] = 0.f;
+  }
+  size_t r, r1, rstep, base = c0;
+  if (POOL) { const int r0 = blockIdx.x * rpc; r = r0 + myr; r1 = min(HW, r0 + rpc); rstep = lanes_r; base += (size_t)blockIdx.y * HW * C; }
+  else { r = (size_t)blockIdx.x * lanes_r + myr; r1 = rows; rstep = (size_t)gridDim.x * lanes_r; }
+#pragma unroll 2
+  for (; r < r1; r += rstep) {
+    const size_t off = base + r * C;
+    Vec16<T> v = ldg16(y + off), rr, o;
+    if (RES) rr = ldg16(res + off);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float x = v.get(j) * sc[j] + sh[j];
+      if (RES == 1) x += rr.get(j);
+      if (RES == 2) x += rr.get(j) * rs[j] + rh[j];
+      o.set(j, (relu && x < 0.f) ? 0.f : x);
+      if (POOL) acc[j] += o.get(j);
+    }
+    stg16(out + off, o);
+  }
+  if constexpr (POOL) {
+    __shared__ float shs[256 * VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) shs[threadIdx.x * VEC + j] = acc[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int v = c / VEC, j = c - v * VEC;
+      float t = 0.f;
+      for (int q = 0; q < lanes_r; ++q) t += shs[(q * cv + v) * VEC + j];
+      part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * C + c] = t;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm backward.  g = dout * (out > 0) (relu) or dout.  Partial sums per block -> slab [blocks][3][C]:
 //   0: sum g   1: sum g*xhat(y)   2: sum g*xhat(y2) (second BN sharing g: the 1x1 shortcut)
@@ -164,7 +247,8 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const T* __restrict_
 template <typename T, bool SELF, bool DUAL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ outact, const T* __restrict__ y,
                                                             const float* __restrict__ coef, const T* __restrict__ y2,
-                                                            const float* __restrict__ coef2, float* __restrict__ slab, size_t rows, int C) {
+                                                            const float* __restrict__ coef2, float* __restrict__ slab, size_t rows, int C,
+                                                            unsigned long long* __restrict__ facc) {
   constexpr int VEC = Vec16<T>::N;
   const int cv = C / VEC;                 // vectors per row
   const int lanes_r = 256 / cv;           // rows processed concurrently by the block (C <= 256*VEC)
@@ -204,7 +288,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const int k = o / C, c = o - k * C, v = c / VEC, j = c - v * VEC;
     float s = 0.f;
     for (int r = 0; r < lanes_r; ++r) s += shm[(k * 256 + r * cv + v) * VEC + j];
-    slab[((size_t)blockIdx.x * 3 + k) * C + c] = s;
+    if (facc) {                               // fixed point: order-free, no finalize launch; replica blockIdx.x % R
+      const int R = acc_replicas(C);
+      if (k < 2 || DUAL) acc_add_fixed<VQA_ACC_BWD_SHIFT>(facc + ((size_t)(blockIdx.x % R) * 3 + k) * C + c, s, facc + (size_t)R * 3 * C);
+    }
+    else slab[((size_t)blockIdx.x * 3 + k) * C + c] = s;
   }
 }
 
@@ -257,6 +345,65 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     a[j] = bc[c0 + j]; b[j] = bc[C + c0 + j]; c[j] = bc[2 * C + c0 + j];
     if (DUAL) { a2[j] = bc2[c0 + j]; b2[j] = bc2[C + c0 + j]; c2[j] = bc2[2 * C + c0 + j]; }
     if (SELF) { ms[j] = mcoef[c0 + j]; mh[j] = mcoef[C + c0 + j]; }
+  }
+#pragma unroll 2
+  for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
+    const size_t off = r * C + c0;
+    Vec16<T> d = ldg16(dout + off), yy = ldg16(y + off), o, y2v, rr, r2;
+    if (!SELF && outact) o = ldg16(outact + off);
+    if (DUAL) y2v = ldg16(y2 + off);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float g = d.get(j);
+      if (SELF) { if (!(yy.get(j) * ms[j] + mh[j] > 0.f)) g = 0.f; }
+      else if (outact && !(o.get(j) > 0.f)) g = 0.f;
+      rr.set(j, a[j] * g + b[j] * yy.get(j) + c[j]);
+      if (DUAL) r2.set(j, a2[j] * g + b2[j] * y2v.get(j) + c2[j]);
+    }
+    stg16(dy + off, rr);
+    if (DUAL) stg16(dy2 + off, r2);
+  }
+}
+
+// The same map with the finalize folded into the prologue: the column sums arrive as fixed-point accumulators facc[3][C] (+ flag),
+// every thread derives A | B | C of its channels (formulas of bn_bwd_finalize_kernel, training mode), the first workgroup adds
+// d gamma / d beta (and the shortcut BatchNorm's, DUAL) into the gradient buffer.
+template <typename T, bool SELF, bool DUAL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restrict__ dout, const T* __restrict__ outact, const T* __restrict__ y,
+                                    const unsigned long long* __restrict__ facc, const float* __restrict__ gamma, const float* __restrict__ coef,
+                                    float* dgamma, float* dbeta, T* __restrict__ dy, const T* __restrict__ y2, const float* __restrict__ gamma2,
+                                    const float* __restrict__ coef2, float* dgamma2, float* dbeta2, T* __restrict__ dy2, size_t rows, int C,
+                                    double inv_count) {
+  constexpr int VEC = Vec16<T>::N;
+  const int cv = C / VEC, lanes_r = 256 / cv;
+  const int c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
+  const bool writer = blockIdx.x == 0;
+  const int R = acc_replicas(C);
+  const bool bad = facc[(size_t)R * 3 * C] != 0;
+  extern __shared__ float cf[];                // [3 | 6][C]: A, B, C (, A2, B2, C2): one evaluation per channel and workgroup
+  for (int ch = threadIdx.x; ch < C; ch += 256) {
+    double sg = acc_read_fixed<VQA_ACC_BWD_SHIFT>(facc, R, 3, C, 0, ch), sx = acc_read_fixed<VQA_ACC_BWD_SHIFT>(facc, R, 3, C, 1, ch);
+    if (bad) sg = sx = __builtin_nan("");
+    const float mean = coef[2 * C + ch], invstd = coef[3 * C + ch], gi = gamma[ch] * invstd;
+    const float mg = (float)(sg * inv_count), mgx = (float)(sx * inv_count);
+    cf[ch] = gi; cf[C + ch] = -gi * invstd * mgx; cf[2 * C + ch] = gi * (mean * invstd * mgx - mg);
+    if (writer) { dgamma[ch] += (float)sx; dbeta[ch] += (float)sg; }
+    if (DUAL) {
+      double sx2 = acc_read_fixed<VQA_ACC_BWD_SHIFT>(facc, R, 3, C, 2, ch);
+      if (bad) sx2 = __builtin_nan("");
+      const float mean2 = coef2[2 * C + ch], inv2 = coef2[3 * C + ch], gi2 = gamma2[ch] * inv2, mgx2 = (float)(sx2 * inv_count);
+      cf[3 * C + ch] = gi2; cf[4 * C + ch] = -gi2 * inv2 * mgx2; cf[5 * C + ch] = gi2 * (mean2 * inv2 * mgx2 - mg);
+      if (writer) { dgamma2[ch] += (float)sx2; dbeta2[ch] += (float)sg; }
+    }
+  }
+  __syncthreads();
+  float a[VEC], b[VEC], c[VEC], a2[DUAL ? VEC : 1], b2[DUAL ? VEC : 1], c2[DUAL ? VEC : 1], ms[SELF ? VEC : 1], mh[SELF ? VEC : 1];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int ch = c0 + j;
+    a[j] = cf[ch]; b[j] = cf[C + ch]; c[j] = cf[2 * C + ch];
+    if (DUAL) { a2[j] = cf[3 * C + ch]; b2[j] = cf[4 * C + ch]; c2[j] = cf[5 * C + ch]; }
+    if (SELF) { ms[j] = coef[ch]; mh[j] = coef[C + ch]; }
   }
 #pragma unroll 2
   for (size_t r = (size_t)blockIdx.x * lanes_r + myr; r < rows; r += (size_t)gridDim.x * lanes_r) {
@@ -560,7 +707,7 @@ template <typename T, bool BNRED>
 __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__ dout, const float* __restrict__ scale, const float* __restrict__ dpool,
                                                            T* __restrict__ dx, unsigned npix, int HW, int C, unsigned long long mul_hw,
                                                            const T* __restrict__ xmask, const T* __restrict__ bn_y, const float* __restrict__ bn_coef,
-                                                           float* __restrict__ bn_slab) {
+                                                           float* __restrict__ bn_slab, unsigned long long* __restrict__ bn_facc) {
   constexpr int VEC = Vec16<T>::N;
   const float inv = 1.f / (float)HW;
   const int cv = C / VEC, lanes_r = 256 / cv, c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
@@ -606,7 +753,11 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
       const int k = o2 / C, c = o2 - k * C, v = c / VEC, j = c - v * VEC;
       float t = 0.f;
       if (k < 2) for (int r = 0; r < lanes_r; ++r) t += shm[(k * 256 + r * cv + v) * VEC + j];
-      bn_slab[((size_t)blockIdx.x * 3 + k) * C + c] = t;
+      if (bn_facc) {
+        const int R = acc_replicas(C);
+        if (k < 2) acc_add_fixed<VQA_ACC_BWD_SHIFT>(bn_facc + ((size_t)(blockIdx.x % R) * 3 + k) * C + c, t, bn_facc + (size_t)R * 3 * C);
+      }
+      else bn_slab[((size_t)blockIdx.x * 3 + k) * C + c] = t;
     }
   }
 }
@@ -840,16 +991,57 @@ int vqa_bn_apply_pool(int dtype, const void* y, const float* coef, const void* r
 #undef BN_APPLYP
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
+// Train-mode BatchNorm apply whose statistics are fixed-point accumulators acc[2*C + 1] (filled by the producing conv launched
+// with stats_mode = 1): finalize + running-statistics update + apply (+ residual | + BatchNorm(res) from racc, + ReLU) in ONE launch;
+// coef_out / rcoef_out [4][C] are published for the backward.  pool_part != NULL: the SE-pooling variant (vqa_bn_apply_pool).
+// 64-bit words of a fixed-point accumulator for K sums of C channels (replicas + flag, even): what the caller zeroes and passes
+int vqa_bn_acc_words(int K, int C) { const long long w = (long long)acc_replicas(C) * K * C + 1; return (int)((w + 1) / 2 * 2); }
+int vqa_bn_apply_acc(int dtype, const void* y, const unsigned long long* acc, const float* gamma, const float* beta, float* rm, float* rv,
+                     long long* nbt, float* coef_out, const void* res, const unsigned long long* racc, const float* rgamma, const float* rbeta,
+                     float* rrm, float* rrv, long long* rnbt, float* rcoef_out, void* out, int B, int HW, int C, int relu, double count,
+                     float momentum, float eps, float* pool_part, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  if (!y || !acc || !gamma || !beta || !coef_out || !out || B <= 0 || HW <= 0 || C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  if (racc && (!res || !rgamma || !rbeta || !rcoef_out)) return VQA_EARG;
+  if (pool_part && racc) return VQA_EARG;
+  BnAcc f = {acc, gamma, beta, rm, rv, nbt, coef_out}, fr = {racc, rgamma, rbeta, rrm, rrv, rnbt, rcoef_out};
+  const size_t rows = (size_t)B * HW;
+  const int lanes_r = 256 / (C / VEC);
+  int g1 = row_grid(rows, lanes_r);
+  if (g1 > 2048) g1 = 2048;                    // the per-workgroup coefficient prologue is amortised over >= ~4 passes
+  dim3 grid(g1);
+  int rpc = 0;
+  const double inv_count = 1.0 / count, unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
+  const size_t shm = (size_t)(racc ? 4 : 2) * C * sizeof(float);
+  if (pool_part) {
+    const int chunks = vqa_bn_apply_pool_chunks(dtype, HW, C);
+    if (chunks <= 0 || B > 65535) return VQA_EARG;
+    rpc = pool_rpc(C, VEC); grid = dim3(chunks, B);
+  }
+#define BN_ACC(TT, R, PL) hipLaunchKernelGGL((bn_apply_acc_kernel<TT, R, PL>), grid, dim3(256), shm, st, (const TT*)y, f, (const TT*)res, fr, (TT*)out, rows, HW, C, \
+    relu, rpc, inv_count, unbias, momentum, eps, pool_part)
+  const int mode = !res ? 0 : (racc ? 2 : 1);
+  if (dtype) {
+    if (pool_part) { if (mode == 0) BN_ACC(bf16_t, 0, true); else BN_ACC(bf16_t, 1, true); }
+    else { if (mode == 0) BN_ACC(bf16_t, 0, false); else if (mode == 1) BN_ACC(bf16_t, 1, false); else BN_ACC(bf16_t, 2, false); }
+  } else {
+    if (pool_part) { if (mode == 0) BN_ACC(float, 0, true); else BN_ACC(float, 1, true); }
+    else { if (mode == 0) BN_ACC(float, 0, false); else if (mode == 1) BN_ACC(float, 1, false); else BN_ACC(float, 2, false); }
+  }
+#undef BN_ACC
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
 int vqa_bn_bwd_blocks(long long rows) { long long g = (rows + 63) / 64; return (int)(g > 768 ? 768 : (g < 1 ? 1 : g)); }
 // slab: [vqa_bn_bwd_blocks(rows)][3][C] floats
+// acc_mode = 1: `slab` is a fixed-point accumulator unsigned long long [3*C + 1] (zeroed by the caller) instead of a float slab
 int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const void* y, const float* coef, const void* y2, const float* coef2,
-                      float* slab, long long rows, int C, int self_mask, hipStream_t st) {
+                      float* slab, long long rows, int C, int self_mask, int acc_mode, hipStream_t st) {
   const int VEC = dtype ? 8 : 4;
   if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
   const int nb = vqa_bn_bwd_blocks(rows);
   const size_t shm = (size_t)3 * 256 * VEC * 4;
 #define BWD_RED(TT, S, D) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, S, D>), dim3(nb), dim3(256), shm, st, (const TT*)dout, (const TT*)outact, \
-    (const TT*)y, coef, (const TT*)y2, coef2, slab, (size_t)rows, C)
+    (const TT*)y, coef, (const TT*)y2, coef2, acc_mode ? nullptr : slab, (size_t)rows, C, acc_mode ? (unsigned long long*)slab : nullptr)
   if (self_mask && (y2 || outact)) return VQA_EARG;
   if (dtype) { if (self_mask) BWD_RED(bf16_t, true, false); else if (y2) BWD_RED(bf16_t, false, true); else BWD_RED(bf16_t, false, false); }
   else { if (self_mask) BWD_RED(float, true, false); else if (y2) BWD_RED(float, false, true); else BWD_RED(float, false, false); }
@@ -859,6 +1051,28 @@ int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const voi
 int vqa_bn_bwd_finalize(const float* slab, int nblk, int C, int which, double count, const float* gamma, const float* coef, int training,
                         float* dgamma, float* dbeta, float* bcoef, hipStream_t st) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, slab, nblk, C, which, count, gamma, coef, training, dgamma, dbeta, bcoef);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+// BatchNorm backward apply with the finalize folded in (training mode): facc[3*C + 1] fixed-point sums from vqa_bn_bwd_reduce /
+// vqa_se_bwd in accumulate mode; d gamma / d beta (+=) are written by the first workgroup.  y2 / gamma2 / coef2 / dgamma2 / dbeta2 / dy2:
+// the 1x1 shortcut's BatchNorm sharing g (all or none).  self_mask: ReLU mask recomputed from y (coef scale | shift), outact unused.
+int vqa_bn_bwd_apply_acc(int dtype, const void* dout, const void* outact, const void* y, const unsigned long long* facc, const float* gamma,
+                         const float* coef, float* dgamma, float* dbeta, void* dy, const void* y2, const float* gamma2, const float* coef2,
+                         float* dgamma2, float* dbeta2, void* dy2, long long numel, int C, double count, int self_mask, hipStream_t st) {
+  const int VEC = dtype ? 8 : 4;
+  if (!dout || !y || !facc || !gamma || !coef || !dgamma || !dbeta || !dy || C % VEC || numel % C || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
+  if (y2 && (!gamma2 || !coef2 || !dgamma2 || !dbeta2 || !dy2)) return VQA_EARG;
+  if (self_mask && (y2 || outact)) return VQA_EARG;
+  const size_t rows = (size_t)numel / C;
+  int grid = row_grid(rows, 256 / (C / VEC));
+  if (grid > 2048) grid = 2048;
+  const size_t shm = (size_t)(y2 ? 6 : 3) * C * sizeof(float);
+  const double inv_count = 1.0 / count;
+#define BWD_ACC(TT, S, D) hipLaunchKernelGGL((bn_bwd_apply_acc_kernel<TT, S, D>), dim3(grid), dim3(256), shm, st, (const TT*)dout, (const TT*)outact, \
+    (const TT*)y, facc, gamma, coef, dgamma, dbeta, (TT*)dy, (const TT*)y2, gamma2, coef2, dgamma2, dbeta2, (TT*)dy2, rows, C, inv_count)
+  if (dtype) { if (self_mask) BWD_ACC(bf16_t, true, false); else if (y2) BWD_ACC(bf16_t, false, true); else BWD_ACC(bf16_t, false, false); }
+  else { if (self_mask) BWD_ACC(float, true, false); else if (y2) BWD_ACC(float, false, true); else BWD_ACC(float, false, false); }
+#undef BWD_ACC
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_bn_bwd_apply(int dtype, const void* dout, const void* outact, const void* y, const float* bc, void* dy,
@@ -932,7 +1146,7 @@ int vqa_se_bwd_blocks(int dtype, int B, int HW, int C) {
 // mask_out = 1): its backward column sums go to bn_slab[vqa_se_bwd_blocks][3][C] and vqa_bn_bwd_reduce is skipped by the caller.
 int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, const float* w2, const float* pooled, const float* hidden,
                const float* scale, float* scratch, void* dx, float* dw1, float* dw2, int B, int HW, int C, int Cr, int mask_out,
-               const void* bn_y, const float* bn_coef, float* bn_slab, hipStream_t st) {
+               const void* bn_y, const float* bn_coef, float* bn_slab, int bn_acc_mode, hipStream_t st) {
   const int VEC = dtype ? 8 : 4;
   if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
   if ((bn_slab != nullptr) != (bn_y != nullptr) || (bn_slab != nullptr) != (bn_coef != nullptr)) return VQA_EARG;
@@ -944,7 +1158,8 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   if (npix >= (1ull << 28)) return VQA_EARG;
   const int ag = bn_slab ? vqa_se_bwd_blocks(dtype, B, HW, C) : px_grid(npix, C, VEC);
 #define SE_APPLY(TT, R) hipLaunchKernelGGL((se_bwd_apply_kernel<TT, R>), dim3(ag), dim3(256), 0, st, (const TT*)dout, scale, dpool, (TT*)dx, (unsigned)npix, HW, C, \
-    magic40(HW), mask_out ? (const TT*)x : nullptr, (const TT*)bn_y, bn_coef, bn_slab)
+    magic40(HW), mask_out ? (const TT*)x : nullptr, (const TT*)bn_y, bn_coef, bn_acc_mode ? nullptr : bn_slab, \
+    bn_acc_mode ? (unsigned long long*)bn_slab : nullptr)
   if (dtype) { if (bn_slab) SE_APPLY(bf16_t, true); else SE_APPLY(bf16_t, false); }
   else { if (bn_slab) SE_APPLY(float, true); else SE_APPLY(float, false); }
 #undef SE_APPLY

@@ -93,4 +93,39 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) 
   return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Order-independent accumulation of fp32 partial sums across workgroups: FIXED POINT in 64-bit integer atomics.  Integer addition
+// commutes, so the total is bit-identical whatever order the workgroups arrive in (float atomics are not: the train step is
+// bit-reproducible, tests/test_gpu_reproducible.py), and the consumer kernel can read the finished sums in its prologue -- no
+// slab, no separate finalize launch between producer and consumer (60 such launches sat on the critical path of a train step).
+//   acc[k*C + c]: sum k of channel c, scaled by 2^SHIFT;   acc[K*C]: count of partials that were non-finite or outside the
+//   fixed-point range -- the consumer then turns the statistics into NaN (loud), as an fp32 sum would have become inf / NaN.
+// A partial is one workgroup's fp32 sum; |partial| < 2^(62-SHIFT) keeps v * 2^SHIFT exact and inside int64.
+//   BatchNorm statistics (sum y, sum y^2):          SHIFT 24  (|partial| < 2^38; resolution 6e-8)
+//   BatchNorm backward (sum g, sum g*xhat):         SHIFT 40  (|partial| < 2^22; resolution 9e-13: gradients are small numbers)
+// ------------------------------------------------------------------------------------------------------------------
+// Replicas: a sum lives in R copies (producer workgroup w adds to copy w % R, the consumer adds the copies as integers) because
+// atomics on ONE address are serialised at ~21 ns each on MI355X (tools/atomic_bench.hip: 768 workgroups x 256 addresses 57 us with
+// one copy, 4 us with eight); R = 512 / C clamped to 1..8 keeps R*C constant, so a consumer prologue reads the same few KB whatever C.
+//   layout: acc[(r*K + k)*C + c] for replica r, sum k, channel c;  flag at acc[R*K*C];  vqa_bn_acc_words(K, C) words in all.
+static inline __host__ __device__ int acc_replicas(int C) { const int r = 512 / (C > 0 ? C : 1); return r < 1 ? 1 : (r > 8 ? 8 : r); }
+#define VQA_ACC_FWD_SHIFT 24
+#define VQA_ACC_BWD_SHIFT 40
+template <int SHIFT>
+__device__ __forceinline__ void acc_add_fixed(unsigned long long* acc, float v, unsigned long long* flag) {
+  constexpr float lim = (float)(1ull << (62 - SHIFT)), scale = (float)(1ull << SHIFT);
+  if (fabsf(v) < lim) atomicAdd(acc, (unsigned long long)__float2ll_rn(v * scale));      // (NaN fails the comparison too)
+  else atomicAdd(flag, 1ull);
+}
+// sum k of channel c over the R <= 8 replicas (integer addition: exact, order-free), as a double.  All loads are issued before
+// the first add: a serial loop over a runtime R is a chain of dependent L2 latencies (24 of them cost a consumer 12 us).
+template <int SHIFT>
+__device__ __forceinline__ double acc_read_fixed(const unsigned long long* acc, int R, int K, int C, int k, int c) {
+  long long v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = r < R ? (long long)acc[((size_t)r * K + k) * C + c] : 0ll;
+  const long long t = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  return (double)t * (1.0 / (double)(1ull << SHIFT));
+}
+
 #define VQA_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -27,6 +27,7 @@ __device__ __forceinline__ int patch_off(int prow, int pcol, int chunk, int PWc)
 
 struct C64Params {
   const bf16_t* x; const bf16_t* w; bf16_t* out; float* stats; const bf16_t* addend; const bf16_t* addmask;
+  int stats_mode;            // 1: stats is a fixed-point accumulator u64 [2*64 + 1] (common.h acc_add_fixed), not a per-workgroup slab
   int B, H, W; unsigned x_bytes;
   int dbg;                        // VQA_C64P_DBG (measurement only, wrong results): bit 0 no epilogue, bit 1 no MFMA loop, bit 2 no in-loop DMA
 };
@@ -330,8 +331,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { s += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
-      p.stats[((size_t)blockIdx.x * 2) * 64 + tid] = s;
-      p.stats[((size_t)blockIdx.x * 2 + 1) * 64 + tid] = q;
+      if (p.stats_mode) {
+        const int R = acc_replicas(64);
+        unsigned long long* fa = reinterpret_cast<unsigned long long*>(p.stats);
+        unsigned long long* fr = fa + (size_t)(blockIdx.x % R) * 128;
+        acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + tid, s, fa + (size_t)R * 128);
+        acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + 64 + tid, q, fa + (size_t)R * 128);
+      } else {
+        p.stats[((size_t)blockIdx.x * 2) * 64 + tid] = s;
+        p.stats[((size_t)blockIdx.x * 2 + 1) * 64 + tid] = q;
+      }
     }
   }
 }
@@ -880,7 +889,7 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
   if (!x || !w || !out || grid <= 0) return VQA_EARG;
   C64Params p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
-  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.B = B; p.H = H; p.W = W; p.dbg = 0;
+  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.B = B; p.H = H; p.W = W; p.dbg = 0; p.stats_mode = 0;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb;
@@ -899,12 +908,12 @@ int vqa_conv3x3_c64p_blocks(int B, int H, int W) {
   return nb < 256 ? nb : 256;
 }
 // forward / addend-free data gradient of the 64 -> 64 channel 3x3 conv with the 8-wave LDS-DMA patch kernel (no epilogue inputs)
-int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, hipStream_t st) {
+int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, int stats_mode, hipStream_t st) {
   const int grid = vqa_conv3x3_c64p_blocks(B, H, W);
   if (!x || !w || !out || grid <= 0) return VQA_EARG;
   C64Params p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats; p.addend = nullptr; p.addmask = nullptr;
-  p.B = B; p.H = H; p.W = W;
+  p.B = B; p.H = H; p.W = W; p.stats_mode = stats_mode;
   const int dbg_env = vqa_env_int("VQA_C64P_DBG", 0);
   p.dbg = dbg_env;
   const size_t xb = (size_t)B * H * W * CH * 2;

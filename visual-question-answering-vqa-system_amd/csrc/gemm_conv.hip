@@ -20,6 +20,7 @@ struct IGemmParams {
   const void* a; const void* w; void* out;
   const float* bias; const void* addend; const void* addmask; float* stats;
   const void* outmask;       // != nullptr: out = (... + addend) * (outmask > 0): the consumer's ReLU mask applied by the producer
+  int stats_mode;            // 0: stats is a float slab [tiles][2][N]; 1: a fixed-point accumulator u64 [2*N + 1] (common.h acc_add_fixed)
   int M, N, Kp, Kw;          // Kp: reduction length rounded up to BK; Kw: weight row length (elements)
   int B, H, W, C;            // source tensor (NHWC; NCHW fp32 image for the stem loader)
   int Ho, Wo;                // spatial dims of the GEMM rows (M = B*Ho*Wo)
@@ -569,8 +570,17 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
         }
         const int n = n0 + cb * 16 + sli;                     // D[i][j]: lane holds column j = l&15, rows 4*(l>>4) + r
         if (n < p.N) {
-          if (sg == 0) p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = dsum[0];
-          if (sg == sq) p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = spp == 0 ? dsq[0] : spp == 1 ? dsq[1] : spp == 2 ? dsq[2] : dsq[3];
+          const float qv = spp == 0 ? dsq[0] : spp == 1 ? dsq[1] : spp == 2 ? dsq[2] : dsq[3];
+          if (p.stats_mode) {                                  // order-free fixed-point sums: the consumer finalizes them itself
+            const int R = acc_replicas(p.N);
+            unsigned long long* fa = reinterpret_cast<unsigned long long*>(p.stats);
+            unsigned long long* fr = fa + (size_t)(tile_m % R) * 2 * p.N;
+            if (sg == 0) acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + n, dsum[0], fa + (size_t)R * 2 * p.N);
+            if (sg == sq) acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + p.N + n, qv, fa + (size_t)R * 2 * p.N);
+          } else {
+            if (sg == 0) p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = dsum[0];
+            if (sg == sq) p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = qv;
+          }
         }
       }
     }
@@ -580,8 +590,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
-      p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = s;
-      p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = q;
+      if (p.stats_mode) {
+        const int R = acc_replicas(p.N);
+        unsigned long long* fa = reinterpret_cast<unsigned long long*>(p.stats);
+        unsigned long long* fr = fa + (size_t)(tile_m % R) * 2 * p.N;
+        acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + n, s, fa + (size_t)R * 2 * p.N);
+        acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + p.N + n, q, fa + (size_t)R * 2 * p.N);
+      } else {
+        p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = s;
+        p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = q;
+      }
     }
   }
   constexpr int VR = BN / VEC, RP = NTHR / VR;
@@ -1511,7 +1529,7 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
               const void* addend, const void* addmask, const void* outmask, float* stats,
               int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
-              hipStream_t st) {
+              int stats_mode, hipStream_t st) {
   if (M <= 0 || N <= 0 || !a || !w || !out) return VQA_EARG;
   const int VEC = dtype ? 8 : 4, BK = dtype ? 64 : 32;
   if (loader == LOADER_NHWC) {
@@ -1525,6 +1543,7 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
   if (drop_p > 0.f && (unsigned long long)M * (unsigned long long)N >= (1ull << 32)) return VQA_EARG;   // 32-bit dropout counter
   IGemmParams p;
   p.a = a; p.w = w; p.out = out; p.bias = bias; p.addend = addend; p.addmask = addmask; p.stats = stats; p.outmask = outmask;
+  p.stats_mode = stats_mode;
   p.M = M; p.N = N; p.Kw = Kw; p.Kp = (Kw + BK - 1) / BK * BK;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
   p.transposed = transposed; p.relu = relu; p.drop_p = drop_p; p.drop_seed = drop_seed; p.a2 = nullptr;
@@ -1555,6 +1574,7 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
   if (!dy || !wt || !out || (Ho & 1) || (Wo & 1) || C % BK || N % VEC || R > 3 || R < 1) return VQA_EARG;
   IGemmParams p;
   p.a = dy; p.a2 = dyd; p.w = wt; p.out = out; p.bias = nullptr; p.addend = nullptr; p.addmask = nullptr; p.stats = nullptr; p.outmask = nullptr;
+  p.stats_mode = 0;
   p.N = N; p.Kw = R * R * C + (dyd ? C : 0); p.Kp = p.Kw; p.M = B * Ho * Wo;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = R; p.stride = 2; p.pad = pad;
   p.transposed = 1; p.relu = 0; p.drop_p = 0.f; p.drop_seed = 0;

@@ -94,6 +94,12 @@ class HipEngine:
         self.use_c64p = True                      # 8-wave weights-resident stage-1 conv kernel
         self.fuse_se_pool = True                  # SE global-average-pool sums leave the last block's bn_apply (one read of the stage output less)
         self.fuse_se_bnred = True                 # the last block's bn2-backward column sums leave the SE backward apply pass (ditto)
+        # BatchNorm finalize folded into the consumers (bf16 training schedule): statistics / backward sums travel as fixed-point
+        # integer accumulators (order-free atomics), so conv -> [finalize] -> apply and reduce -> [finalize] -> apply lose their
+        # middle launches (60 per step on the critical path; upper bound measured with tools/ab_nofinalize.py: -0.5 ms of 12.9)
+        self.fuse_bn_finalize = True
+        self._accbuf = None
+        self._accpos = 0
         self._stem_fcoef = None
         self.fold_eval = True                     # inference (eval, no tape): Conv+BN folded, BN never runs as its own pass
         self._fold = None                         # (key, table, nd, blocks, wbuf, bbuf, views)
@@ -230,6 +236,26 @@ class HipEngine:
         return K.bn_eval_coef(C, self.P(prefix + ".weight"), self.P(prefix + ".bias"),
                               self.buf[prefix + ".running_mean"], self.buf[prefix + ".running_var"])
 
+    # ---- fixed-point accumulators: ONE zeroed int64 buffer per forward (statistics) and per backward (column sums), sliced
+    ACC_WORDS = 96 * 1024
+
+    def _acc_reset(self):
+        self._accbuf = torch.zeros(self.ACC_WORDS, device=self.flat.device, dtype=torch.int64)
+        self._accpos = 0
+
+    def _acc(self, words):
+        words = (words + 1) // 2 * 2                       # 16-byte aligned slices
+        if self._accbuf is None or self._accpos + words > self._accbuf.numel():
+            self._accbuf = torch.zeros(max(self.ACC_WORDS, words), device=self.flat.device, dtype=torch.int64)
+            self._accpos = 0
+        t = self._accbuf[self._accpos: self._accpos + words]
+        self._accpos += words
+        return t
+
+    def _bn_params(self, prefix, training=True):
+        return (self.P(prefix + ".weight"), self.P(prefix + ".bias"), self.buf[prefix + ".running_mean"], self.buf[prefix + ".running_var"],
+                self.buf[prefix + ".num_batches_tracked"])
+
     def _c64_ok(self, B, H, W, Cin, Cout, R, stride, wgrad=False):
         if not wgrad and not self.use_c64_fwd:
             return False          # since the LDS-DMA rewrite the generic implicit GEMM is as fast for forward / data gradient
@@ -250,18 +276,22 @@ class HipEngine:
         n, c = e.shape[0], e.shape[1]
         return self._packT(name + ".flip", [(e.offset, n, 9, c, 0, True)], c, 9 * n)
 
-    def _conv(self, x, B, H, W, Cin, wname, Cout, R, stride, pad, stats):
+    def _conv(self, x, B, H, W, Cin, wname, Cout, R, stride, pad, stats, acc=False):
+        """acc: the BatchNorm sums go to a fixed-point accumulator (returned in the slab's place, mtiles = -1) when the kernel that
+        runs this shape supports it; otherwise the usual slab comes back and the caller runs the finalize launch."""
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
         M = B * Ho * Wo
         geom = (B, H, W, Cin, Ho, Wo, R, R, stride, pad)
         if self._c64p_ok(B, H, W, Cin, Cout, R, stride):
-            y, st, mt = K.conv3x3_c64p(x, self.Wm(wname), B, H, W, want_stats=stats)
-            return y, st, mt, geom, Ho, Wo
+            a = self._acc(K.L.count("vqa_bn_acc_words", 2, Cout)) if (acc and stats) else None
+            y, st, mt = K.conv3x3_c64p(x, self.Wm(wname), B, H, W, want_stats=stats, stats_acc=a)
+            return y, st, (-1 if a is not None else mt), geom, Ho, Wo
         if self._c64_ok(B, H, W, Cin, Cout, R, stride):
             y, st, mt = K.conv3x3_c64(x, self.Wm(wname), B, H, W, want_stats=stats)
             return y, st, mt, geom, Ho, Wo
-        y, st, mt = K.igemm(x, self.Wm(wname), M, Cout, R * R * Cin, geom, dtype=self.dtype, want_stats=stats)
-        return y, st, mt, geom, Ho, Wo
+        a = self._acc(K.L.count("vqa_bn_acc_words", 2, Cout)) if (acc and stats) else None
+        y, st, mt = K.igemm(x, self.Wm(wname), M, Cout, R * R * Cin, geom, dtype=self.dtype, want_stats=stats, stats_acc=a)
+        return y, st, (-1 if a is not None else mt), geom, Ho, Wo
 
     def _lin(self, x, wname, bname=None, relu=0, p=0.0, seed=0, addend=None):
         e = self.E[wname]
@@ -431,6 +461,8 @@ class HipEngine:
         if training:
             self.step_id += 1
         self.begin_step(for_backward=need_tape)
+        if training and self.fuse_bn_finalize and T == torch.bfloat16:
+            self._acc_reset()                     # one memset for every BatchNorm accumulator of this forward
         tape: dict = {"training": training, "B": images.shape[0]}
         B, _, IH, IW = images.shape
         pdrop = cfg["dropout"] if training else 0.0
@@ -508,21 +540,39 @@ class HipEngine:
                     out, _, _ = K.igemm(a1, w2, M, Cout, 9 * Cout, (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1), dtype=T, bias=b2, addend=res, relu=2)
                     x, H, W, C = out, Ho, Wo, Cout
                     continue
-                y1, st1, mt1, g1, Ho, Wo = self._conv(x, B, H, W, Cin, p + ".conv1.weight", Cout, 3, stride, 1, training)
+                facc = training and self.fuse_bn_finalize and T == torch.bfloat16
+                y1, st1, mt1, g1, Ho, Wo = self._conv(x, B, H, W, Cin, p + ".conv1.weight", Cout, 3, stride, 1, training, acc=facc)
                 M = B * Ho * Wo
-                c1 = self._bn_coef(p + ".bn1", st1, mt1, Cout, M, training)
-                a1 = K.bn_apply(y1, c1, Cout, relu=True)
-                y2, st2, mt2, g2, _, _ = self._conv(a1, B, Ho, Wo, Cout, p + ".conv2.weight", Cout, 3, 1, 1, training)
-                c2 = self._bn_coef(p + ".bn2", st2, mt2, Cout, M, training)
+                if mt1 < 0:                                  # statistics in a fixed-point accumulator: finalize + apply in one launch
+                    a1, c1, _, _, _ = K.bn_apply_acc(y1, st1, self._bn_params(p + ".bn1"), Cout, True, B, Ho * Wo, M)
+                else:
+                    c1 = self._bn_coef(p + ".bn1", st1, mt1, Cout, M, training)
+                    a1 = K.bn_apply(y1, c1, Cout, relu=True)
+                y2, st2, mt2, g2, _, _ = self._conv(a1, B, Ho, Wo, Cout, p + ".conv2.weight", Cout, 3, 1, 1, training, acc=facc)
+                c2 = None if mt2 < 0 else self._bn_coef(p + ".bn2", st2, mt2, Cout, M, training)
                 rec = dict(p=p, x=x, y1=y1, c1=c1, a1=a1, y2=y2, c2=c2, g1=g1, g2=g2, M=M, Cin=Cin, Cout=Cout)
                 # the stage's last block hands the SE pooling sums over (its output is the SE input)
                 pool_here = (b == 1 and self.fuse_se_pool and (f"image_encoder.stage{s}.attention.se.fc1.weight") in self.E
                              and K.L.count("vqa_bn_apply_pool_chunks", dt(T), Ho * Wo, Cout) > 0 and B <= 65535)
                 if (p + ".downsample.0.weight") in self.E:
-                    yd, std, mtd, gd, _, _ = self._conv(x, B, H, W, Cin, p + ".downsample.0.weight", Cout, 1, stride, 0, training)
-                    cd = self._bn_coef(p + ".downsample.1", std, mtd, Cout, M, training)
-                    out = K.bn_apply(y2, c2, Cout, relu=True, res=yd, rcoef=cd)
+                    yd, std, mtd, gd, _, _ = self._conv(x, B, H, W, Cin, p + ".downsample.0.weight", Cout, 1, stride, 0, training,
+                                                        acc=facc and mt2 < 0)
+                    if mt2 < 0 and mtd < 0:                  # both BatchNorms finalized inside the residual-add pass
+                        out, c2, cd, _, _ = K.bn_apply_acc(y2, st2, self._bn_params(p + ".bn2"), Cout, True, B, Ho * Wo, M, res=yd, racc=std,
+                                                           rbn=self._bn_params(p + ".downsample.1"))
+                        rec["c2"] = c2
+                    else:
+                        if mt2 < 0:
+                            raise RuntimeError("fixed-point statistics of conv2 without those of the shortcut conv")
+                        cd = self._bn_coef(p + ".downsample.1", std, mtd, Cout, M, training)
+                        out = K.bn_apply(y2, c2, Cout, relu=True, res=yd, rcoef=cd)
                     rec.update(yd=yd, cd=cd, gd=gd)
+                elif mt2 < 0:
+                    out, c2, _, pool_part, pool_chunks = K.bn_apply_acc(y2, st2, self._bn_params(p + ".bn2"), Cout, True, B, Ho * Wo, M, res=x,
+                                                                        pool=pool_here)
+                    rec["c2"] = c2
+                    if pool_here:
+                        srec["pool"] = (pool_part, pool_chunks)
                 elif pool_here:
                     out, pool_part, pool_chunks = K.bn_apply_pool(y2, c2, Cout, True, B, Ho * Wo, res=x)
                     srec["pool"] = (pool_part, pool_chunks)
@@ -800,6 +850,10 @@ class HipEngine:
             ev_tb = torch.cuda.Event(); ev_tb.record()
 
         # ---- CNN stages (reverse)
+        bwd_acc = training and self.fuse_bn_finalize and T == torch.bfloat16
+        self._bwd_acc = bwd_acc
+        if bwd_acc:
+            self._acc_reset()                     # one memset for every BatchNorm-backward accumulator of this backward
         dxc = dfeat
         masked = False           # True: dxc already carries the ReLU mask of the block that consumes it (see _block_bwd)
         for s in (4, 3, 2, 1):
@@ -823,12 +877,15 @@ class HipEngine:
                 se_pre = None
                 if self.fuse_se_bnred and "yd" not in lastb:
                     nblk = K.L.count("vqa_se_bwd_blocks", dt(T), B, r["HW"], r["C"])
-                    if nblk > 0:
+                    if nblk > 0 and bwd_acc:
+                        se_pre = (self._acc(K.L.count("vqa_bn_acc_words", 3, r["C"])), -1)      # fixed-point accumulator: the block's apply pass finalizes it
+                    elif nblk > 0:
                         se_pre = (torch.empty((nblk, 3, r["C"]), device=dxc.device, dtype=torch.float32), nblk)
                 call("vqa_se_bwd", dt(T), ptr(dxc), ptr(r["x"]), ptr(self.P(ap + ".se.fc1.weight")), ptr(self.P(ap + ".se.fc2.weight")),
                      ptr(r["pooled"]), ptr(r["hidden"]), ptr(r["scale"]), ptr(scratch), ptr(dxn),
                      ptr(self._gslice(G, ap + ".se.fc1.weight")), ptr(self._gslice(G, ap + ".se.fc2.weight")), B, r["HW"], r["C"], r["Cr"], 1,
-                     ptr(lastb["y2"]) if se_pre else None, ptr(lastb["c2"]) if se_pre else None, ptr(se_pre[0]) if se_pre else None)
+                     ptr(lastb["y2"]) if se_pre else None, ptr(lastb["c2"]) if se_pre else None, ptr(se_pre[0]) if se_pre else None,
+                     int(bool(se_pre) and se_pre[1] < 0))
                 dxc = dxn
                 masked = True                 # the SE input IS the last block's post-ReLU output: its mask was applied on the way out
             else:
@@ -886,7 +943,7 @@ class HipEngine:
         rows_p = pooled.numel() // 64
         nb = K.L.count("vqa_bn_bwd_blocks", rows_p)
         slab = torch.empty((nb, 3, 64), device=dxc.device, dtype=torch.float32)
-        call("vqa_bn_bwd_reduce", dt(T), ptr(dxc), ptr(pooled), ptr(pooled), ptr(fcoef), None, None, ptr(slab), rows_p, 64, 0)
+        call("vqa_bn_bwd_reduce", dt(T), ptr(dxc), ptr(pooled), ptr(pooled), ptr(fcoef), None, None, ptr(slab), rows_p, 64, 0, 0)
         bc = torch.empty((3, 64), device=dxc.device, dtype=torch.float32)
         bnp = "image_encoder.stem.1"
         call("vqa_bn_bwd_finalize", ptr(slab), nb, 64, 1, float(B * H1 * W1), ptr(self.P(bnp + ".weight")), ptr(st["coef"]),
@@ -923,13 +980,16 @@ class HipEngine:
         last = p == "image_encoder.stage1.blocks.0"           # its weight gradients are released with the stem backward (deferring all of stage 1 measured worse)
         gs = lambda n: self._gslice(G, n)
         out_act = None if masked else rec["out"]
+        bacc = getattr(self, "_bwd_acc", False)
+        pre_acc = pre is not None and pre[1] < 0             # the SE backward already filled a fixed-point accumulator for bn2
         dy2, dyd = K.bn_bwd(dout, out_act, rec["y2"], rec["c2"], self.P(p + ".bn2.weight"), Cout, training,
                             gs(p + ".bn2.weight"), gs(p + ".bn2.bias"),
                             y2=rec.get("yd"), coef2=rec.get("cd"),
                             gamma2=self.P(p + ".downsample.1.weight") if has_ds else None,
                             dgamma2=gs(p + ".downsample.1.weight") if has_ds else None,
                             dbeta2=gs(p + ".downsample.1.bias") if has_ds else None,
-                            slab=pre[0] if pre else None, nb=pre[1] if pre else 0)
+                            slab=pre[0] if (pre and not pre_acc) else None, nb=pre[1] if (pre and not pre_acc) else 0,
+                            facc=(pre[0] if pre_acc else (self._acc(K.L.count("vqa_bn_acc_words", 3, Cout)) if bacc else None)), facc_filled=pre_acc)
         g2 = rec["g2"]; B, Ho, Wo = g2[0], g2[1], g2[2]
         c64_2 = self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1)
         if self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1, wgrad=True):
@@ -948,7 +1008,7 @@ class HipEngine:
             da1, _, _ = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1)
         dy1, _ = K.bn_bwd(da1, None, rec["y1"], rec["c1"], self.P(p + ".bn1.weight"), Cout, training,
                           gs(p + ".bn1.weight"), gs(p + ".bn1.bias"), self_mask=True,      # a1 > 0 recomputed from y1: a1 is not read
-                          slab=slab1, nb=nb1)
+                          slab=slab1, nb=nb1, facc=self._acc(K.L.count("vqa_bn_acc_words", 3, Cout)) if bacc else None)
         g1 = rec["g1"]; H, W, stride = g1[1], g1[2], g1[8]
         c64_1 = self._c64_ok(B, H, W, Cin, Cout, 3, stride)
         if self._c64_ok(B, H, W, Cin, Cout, 3, stride, wgrad=True):

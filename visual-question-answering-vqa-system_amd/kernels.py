@@ -31,6 +31,8 @@ HBM_BYTES = {
     "vqa_bn_apply": ("bn", lambda a: a[6] * _ES(a[0]) * (2 + _P(a[3]))),
     "vqa_bn_apply_pool": ("bn", lambda a: a[6] * a[7] * a[8] * _ES(a[0]) * (2 + _P(a[3]))),
     "vqa_bn_bwd_reduce": ("bn", lambda a: a[8] * a[9] * _ES(a[0]) * (2 + _P(a[2]) + _P(a[5]))),
+    "vqa_bn_apply_acc": ("bn", lambda a: a[18] * a[19] * a[20] * _ES(a[0]) * (2 + _P(a[9]))),
+    "vqa_bn_bwd_apply_acc": ("bn", lambda a: a[16] * _ES(a[0]) * (3 + _P(a[2]) + 2 * _P(a[10]))),
     "vqa_bn_bwd_finalize": ("bn", lambda a: a[1] * a[2] * 3 * 4),
     "vqa_bn_bwd_apply": ("bn", lambda a: a[9] * _ES(a[0]) * (3 + _P(a[2]) + 2 * _P(a[6]))),
     "vqa_stem_pool_fwd": ("stem_pool", lambda a: a[5] * a[6] * a[7] * a[8] * _ES(a[0])
@@ -145,15 +147,16 @@ def c64p_blocks(B, H, W) -> int:
     return L.count("vqa_conv3x3_c64p_blocks", B, H, W)
 
 
-def conv3x3_c64p(x, w, B, H, W, *, want_stats=False):
-    """bf16 3x3/1 conv, 64->64 channels, 8-wave LDS-DMA patch kernel (no epilogue inputs).  Returns (out, stats slab | None, blocks)."""
+def conv3x3_c64p(x, w, B, H, W, *, want_stats=False, stats_acc=None):
+    """bf16 3x3/1 conv, 64->64 channels, 8-wave LDS-DMA patch kernel (no epilogue inputs).  Returns (out, stats slab | None, blocks).
+    stats_acc: a zeroed int64 [2*64 + 1] fixed-point accumulator that receives the BatchNorm sums instead of a slab."""
     nb = c64p_blocks(B, H, W)
     out = torch.empty((B * H * W, 64), device=x.device, dtype=torch.bfloat16)
-    stats = torch.empty((nb, 2, 64), device=x.device, dtype=torch.float32) if want_stats else None
+    stats = torch.empty((nb, 2, 64), device=x.device, dtype=torch.float32) if (want_stats and stats_acc is None) else stats_acc
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("vqa_conv3x3_c64p", ptr(x), ptr(w), ptr(out), ptr(stats), B, H, W)
+    call("vqa_conv3x3_c64p", ptr(x), ptr(w), ptr(out), ptr(stats), B, H, W, int(stats_acc is not None))
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("conv3x3_c64p_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
@@ -244,21 +247,22 @@ def stem_conv(img, wstem, B, H, W, want_stats):
 
 
 def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=None, addmask=None, outmask=None, want_stats=False,
-          transposed=0, relu=0, drop_p=0.0, drop_seed=0, out=None):
+          transposed=0, relu=0, drop_p=0.0, drop_seed=0, out=None, stats_acc=None):
     """out[M][N] = gather(a) @ w[N][Kw]^T with the fused epilogue.  geom = (B, H, W, C, Ho, Wo, R, S, stride, pad).
-    Returns (out, stats_slab | None, mtiles)."""
+    Returns (out, stats_slab | None, mtiles).  stats_acc: a zeroed int64 [2*N + 1] fixed-point accumulator that receives the
+    BatchNorm sums instead of a slab (returned in the slab's place, mtiles = 0)."""
     B, H, W, C, Ho, Wo, R, S, stride, pad = geom
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=dtype)
-    stats, mt = None, 0
-    if want_stats:
+    stats, mt = stats_acc, 0
+    if want_stats and stats_acc is None:
         mt = L.count("vqa_igemm_mtiles", M, N, loader)
         stats = torch.empty((mt, 2, N), device=a.device, dtype=torch.float32)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     call("vqa_igemm", dt(dtype), loader, ptr(a), ptr(w), ptr(out), ptr(bias), ptr(addend), ptr(addmask), ptr(outmask), ptr(stats),
-         M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad, transposed, relu, float(drop_p), int(drop_seed))
+         M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad, transposed, relu, float(drop_p), int(drop_seed), int(stats_acc is not None))
     if PROFILE is not None:
         e1.record()
         var = igemm_variant(dtype, loader, M, N, Kw, geom)
@@ -366,6 +370,23 @@ def bn_apply(y, coef, C, relu, res=None, rcoef=None):
     return out
 
 
+def bn_apply_acc(y, acc, bn, C, relu, B, HW, count, *, res=None, racc=None, rbn=None, pool=False, momentum=0.1, eps=1e-5):
+    """Train-mode BatchNorm apply with the statistics finalize folded in (vqa_bn_apply_acc).  bn / rbn = (gamma, beta, running_mean,
+    running_var, num_batches_tracked).  Returns (out, coef [4][C], rcoef | None, pool part | None, chunks)."""
+    out = torch.empty_like(y)
+    coef = torch.empty((4, C), device=y.device, dtype=torch.float32)
+    rcoef = torch.empty((4, C), device=y.device, dtype=torch.float32) if racc is not None else None
+    part, chunks = None, 0
+    if pool:
+        chunks = L.count("vqa_bn_apply_pool_chunks", dt(y), HW, C)
+        part = torch.empty((B, chunks, C), device=y.device, dtype=torch.float32)
+    g, b_, rm, rv, nbt = bn
+    rg, rb, rrm, rrv, rnbt = rbn if rbn is not None else (None,) * 5
+    call("vqa_bn_apply_acc", dt(y), ptr(y), ptr(acc), ptr(g), ptr(b_), ptr(rm), ptr(rv), ptr(nbt), ptr(coef), ptr(res), ptr(racc), ptr(rg), ptr(rb),
+         ptr(rrm), ptr(rrv), ptr(rnbt), ptr(rcoef), ptr(out), B, HW, C, int(relu), float(count), momentum, eps, ptr(part))
+    return out, coef, rcoef, part, chunks
+
+
 def bn_apply_pool(y, coef, C, relu, B, HW, res=None, rcoef=None):
     """bn_apply of a stage's last block that also leaves the SE pooling sums: returns (out, part [B][chunks][C], chunks)."""
     out = torch.empty_like(y)
@@ -376,15 +397,23 @@ def bn_apply_pool(y, coef, C, relu, B, HW, res=None, rcoef=None):
 
 
 def bn_bwd(dout, outact, y, coef, gamma, C, training, dgamma, dbeta, y2=None, coef2=None, gamma2=None, dgamma2=None, dbeta2=None,
-           self_mask=False, slab=None, nb=0):
+           self_mask=False, slab=None, nb=0, facc=None, facc_filled=False):
     """BatchNorm backward for g = dout*(outact>0); optional second BN (1x1 shortcut) sharing g.
     self_mask: the ReLU directly follows this BN (no residual), so the mask relu(bn(y)) > 0 is recomputed from y and the
     activation tensor is not read at all (pass outact=None).  Returns dy (and dy2)."""
     rows = y.numel() // C
+    if facc is not None:       # fixed-point accumulators + finalize folded into the apply pass (training mode, bf16 schedule)
+        if not facc_filled:
+            call("vqa_bn_bwd_reduce", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(coef), ptr(y2), ptr(coef2), ptr(facc), rows, C, int(self_mask), 1)
+        dy = torch.empty_like(y)
+        dy2 = torch.empty_like(y2) if y2 is not None else None
+        call("vqa_bn_bwd_apply_acc", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(facc), ptr(gamma), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dy),
+             ptr(y2), ptr(gamma2), ptr(coef2), ptr(dgamma2), ptr(dbeta2), ptr(dy2), y.numel(), C, float(rows), int(self_mask))
+        return dy, dy2
     if slab is None:           # (else: the caller already reduced the column sums)
         nb = L.count("vqa_bn_bwd_blocks", rows)
         slab = torch.empty((nb, 3, C), device=y.device, dtype=torch.float32)
-        call("vqa_bn_bwd_reduce", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(coef), ptr(y2), ptr(coef2), ptr(slab), rows, C, int(self_mask))
+        call("vqa_bn_bwd_reduce", dt(y), ptr(dout), ptr(outact), ptr(y), ptr(coef), ptr(y2), ptr(coef2), ptr(slab), rows, C, int(self_mask), 0)
     bc = torch.empty((3, C), device=y.device, dtype=torch.float32)
     call("vqa_bn_bwd_finalize", ptr(slab), nb, C, 1, float(rows), ptr(gamma), ptr(coef), int(training), ptr(dgamma), ptr(dbeta), ptr(bc))
     dy = torch.empty_like(y)
