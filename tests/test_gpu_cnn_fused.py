@@ -117,6 +117,19 @@ def test_se_backward_leaves_the_batchnorm_backward_sums(shape, dtype):
     torch.cuda.synchronize()
     s2 = slab2.sum(0)
     assert (s[0] - s2[0]).abs().max().item() < tol(ref0) and (s[1] - s2[1]).abs().max().item() < tol(ref1)
+    # accumulator mode (what the bf16 training schedule runs: the one-pass-structure kernel + fixed-point sums, common.h)
+    facc = torch.zeros(L.count("vqa_bn_acc_words", 3, C), device=DEV, dtype=torch.int64)
+    scratch = torch.empty(B * (2 * C + Cr), device=DEV)
+    dx3 = torch.empty_like(x); dw13, dw23 = torch.zeros_like(w1), torch.zeros_like(w2)
+    L.call("vqa_se_bwd", L.dt(dtype), dout.data_ptr(), x.data_ptr(), w1.data_ptr(), w2.data_ptr(), pooled.data_ptr(), hidden.data_ptr(),
+           scale.data_ptr(), scratch.data_ptr(), dx3.data_ptr(), dw13.data_ptr(), dw23.data_ptr(), B, HW, C, Cr, 1, y2.data_ptr(), coef.data_ptr(),
+           facc.data_ptr(), 1)
+    torch.cuda.synchronize()
+    assert torch.equal(dx3, dx) and torch.equal(dw13, dw1) and torch.equal(dw23, dw2)
+    R = max(1, min(8, 512 // C))
+    sums = facc[: R * 3 * C].view(R, 3, C).sum(0).double() / float(1 << 40)
+    assert int(facc[R * 3 * C]) == 0
+    assert (sums[0].float() - ref0).abs().max().item() < tol(ref0) and (sums[1].float() - ref1).abs().max().item() < tol(ref1)
     with pytest.raises(RuntimeError):                                       # all three BatchNorm arguments or none
         scratch = torch.empty(B * (2 * C + Cr), device=DEV)
         L.call("vqa_se_bwd", L.dt(dtype), dout.data_ptr(), x.data_ptr(), w1.data_ptr(), w2.data_ptr(), pooled.data_ptr(), hidden.data_ptr(),

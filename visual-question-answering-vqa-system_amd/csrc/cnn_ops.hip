@@ -762,6 +762,116 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// SE backward in ONE pass structure: the workgroup that reduced sample b (phase 1 of se_bwd_reduce_kernel) applies it right away
+// (phase 2 of se_bwd_apply_kernel), so the second read of dout / x of that sample (0.4 MB ... 50 KB each) comes from the caches it
+// just filled (L2 / Infinity Cache) instead of from HBM after the whole batch has streamed through twice.  Same arithmetic in the
+// same order per element as the two-launch form: dx is bit-identical.  BNRED as in se_bwd_apply_kernel (accumulator mode only).
+template <typename T, bool BNRED>
+__global__ __launch_bounds__(256) void se_bwd_fused_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ w1,
+                                                           const float* __restrict__ w2, const float* __restrict__ hidden,
+                                                           const float* __restrict__ scale, float* __restrict__ dz2, float* __restrict__ dh,
+                                                           float* __restrict__ dpool, T* __restrict__ dx, int HW, int C, int Cr, int mask_out,
+                                                           const T* __restrict__ bn_y, const float* __restrict__ bn_coef,
+                                                           unsigned long long* __restrict__ bn_facc) {
+  constexpr int VEC = Vec16<T>::N;
+  extern __shared__ float sh[];            // [256*VEC] scratch | z2[C] | dhs[Cr] | dpl[C] | scl[C]
+  const int b = blockIdx.x, cv = C / VEC, lanes_r = 256 / cv;
+  const int myv = threadIdx.x % cv, myr = threadIdx.x / cv, c0 = myv * VEC;
+  const size_t base = (size_t)b * HW * C + c0;
+  float s[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  {
+    int p = myr;
+    for (; p + lanes_r < HW; p += 2 * lanes_r) {
+      const size_t o0 = base + (size_t)p * C, o1 = base + (size_t)(p + lanes_r) * C;
+      Vec16<T> d0 = ldg16(dout + o0), v0 = ldg16(x + o0), d1 = ldg16(dout + o1), v1 = ldg16(x + o1);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += d0.get(j) * v0.get(j) + d1.get(j) * v1.get(j);
+    }
+    for (; p < HW; p += lanes_r) {
+      const size_t off = base + (size_t)p * C;
+      Vec16<T> d = ldg16(dout + off), v = ldg16(x + off);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += d.get(j) * v.get(j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sh[threadIdx.x * VEC + j] = s[j];
+  __syncthreads();
+  float* z2 = sh + 256 * VEC; float* dhs = z2 + C; float* dpl = dhs + Cr; float* scl = dpl + C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int v = c / VEC, j = c - v * VEC;
+    float t = 0.f;
+    for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
+    const float sg = scale[(size_t)b * C + c];
+    scl[c] = sg;
+    t *= sg * (1.f - sg);
+    z2[c] = t; dz2[(size_t)b * C + c] = t;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int jr = wave; jr < Cr; jr += 4) {
+    float t = 0.f;
+    for (int c = lane; c < C; c += 64) t += z2[c] * w2[(size_t)c * Cr + jr];
+    t = wave_sum(t);
+    if (lane == 0) { t = hidden[(size_t)b * Cr + jr] > 0.f ? t : 0.f; dhs[jr] = t; dh[(size_t)b * Cr + jr] = t; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int jr = 0; jr < Cr; ++jr) t += dhs[jr] * w1[(size_t)jr * C + c];
+    dpl[c] = t; dpool[(size_t)b * C + c] = t;
+  }
+  __syncthreads();
+  // ---- phase 2: dx = dout*scale + dpool/HW (* (x > 0)), this sample only
+  const float inv = 1.f / (float)HW;
+  float sc[VEC], dp[VEC], sg[BNRED ? VEC : 1], sx[BNRED ? VEC : 1], bmean[BNRED ? VEC : 1], binv[BNRED ? VEC : 1];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = scl[c0 + j]; dp[j] = dpl[c0 + j] * inv;
+    if (BNRED) { sg[j] = sx[j] = 0.f; bmean[j] = bn_coef[2 * C + c0 + j]; binv[j] = bn_coef[3 * C + c0 + j]; }
+  }
+#pragma unroll 2
+  for (int p = myr; p < HW; p += lanes_r) {
+    const size_t e = base + (size_t)p * C;
+    Vec16<T> d = ldg16(dout + e), o, xm, yy;
+    if (mask_out) xm = ldg16(x + e);
+    if constexpr (BNRED) yy = ldg16(bn_y + e);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float v = fmaf(d.get(j), sc[j], dp[j]);
+      if (mask_out && !(xm.get(j) > 0.f)) v = 0.f;
+      o.set(j, v);
+      if constexpr (BNRED) { const float g = o.get(j); sg[j] += g; sx[j] += g * (yy.get(j) - bmean[j]) * binv[j]; }
+    }
+    stg16(dx + e, o);
+  }
+  if constexpr (BNRED) {
+    __syncthreads();                         // everyone is done with the phase-1 scratch
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sh[threadIdx.x * VEC + j] = sg[j]; }
+    __syncthreads();
+    const int R = acc_replicas(C);
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int v = c / VEC, j = c - v * VEC;
+      float t = 0.f;
+      for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
+      acc_add_fixed<VQA_ACC_BWD_SHIFT>(bn_facc + ((size_t)(blockIdx.x % R) * 3 + 0) * C + c, t, bn_facc + (size_t)R * 3 * C);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sh[threadIdx.x * VEC + j] = sx[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int v = c / VEC, j = c - v * VEC;
+      float t = 0.f;
+      for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
+      acc_add_fixed<VQA_ACC_BWD_SHIFT>(bn_facc + ((size_t)(blockIdx.x % R) * 3 + 1) * C + c, t, bn_facc + (size_t)R * 3 * C);
+    }
+  }
+}
+
 // dw2[c][j] += sum_b dz2[b][c]*hidden[b][j] ; dw1[j][c] += sum_b dh[b][j]*pooled[b][c]
 // A workgroup owns 8 consecutive (j, c) pairs (c fastest) and splits the batch over 32 thread slices; the slices are folded in LDS
 // in slice order, so every weight has ONE writer and a fixed summation order (bit-reproducible, no atomics, no scratch).
@@ -1152,6 +1262,16 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   if ((bn_slab != nullptr) != (bn_y != nullptr) || (bn_slab != nullptr) != (bn_coef != nullptr)) return VQA_EARG;
   float* dz2 = scratch; float* dh = dz2 + (size_t)B * C; float* dpool = dh + (size_t)B * Cr;
   const size_t shm = ((size_t)256 * VEC + C + Cr) * 4;
+  if (!bn_slab || bn_acc_mode) {             // one pass structure: reduce + apply per sample in the same workgroup
+    const size_t shm2 = ((size_t)256 * VEC + 3 * C + Cr) * 4;
+#define SE_FUSED(TT, R) hipLaunchKernelGGL((se_bwd_fused_kernel<TT, R>), dim3(B), dim3(256), shm2, st, (const TT*)dout, (const TT*)x, w1, w2, hidden, scale, \
+    dz2, dh, dpool, (TT*)dx, HW, C, Cr, mask_out, (const TT*)bn_y, bn_coef, (unsigned long long*)bn_slab)
+    if (dtype) { if (bn_slab) SE_FUSED(bf16_t, true); else SE_FUSED(bf16_t, false); }
+    else { if (bn_slab) SE_FUSED(float, true); else SE_FUSED(float, false); }
+#undef SE_FUSED
+    hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 7) / 8), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
+    VQA_LAUNCH_CHECK(); return VQA_OK;
+  }
   DT(hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, dim3(B), dim3(256), shm, st, (const float*)dout, (const float*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr),
      hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr));
   const size_t npix = (size_t)B * HW;
