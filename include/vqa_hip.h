@@ -69,8 +69,10 @@ int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int 
    supported (the caller uses vqa_wgrad). */
 int vqa_wgrad3x3_c128_blocks(int B, int H, int W);
 int vqa_wgrad3x3_c128(const void* x, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t stream);
+int vqa_wgrad3x3_c64_blocks(int B, int H, int W);   /* [64][576] slabs of scratch vqa_wgrad3x3_c64 wants for this shape (0: unsupported) */
 int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw /* [64][576] += */, int B, int H, int W,
-                     float* ws /* >= vqa_conv3x3_c64_blocks * 64*576 floats of scratch, or NULL: atomics */, long long ws_floats, hipStream_t stream);
+                     float* ws /* >= vqa_wgrad3x3_c64_blocks * 64*576 floats of scratch, or NULL: 4-wave kernel with atomics */,
+                     long long ws_floats, hipStream_t stream);
 /* Up to 8 Linear weight gradients dw_j[N_j][K_j] += dy_j[M_j][N_j]^T x_j[M_j][K_j] in ONE launch + ONE fixed-order reduce launch
    (training/train.py:196 loss.backward() -> the token-side nn.Linear weights of models/text_encoder.py, cross_attention.py, fusion.py,
    answer_head.py).  Each dw_j is bit-identical to its own vqa_wgrad call.  vqa_wgrad_group_ws: floats of the shared workspace, or -1

@@ -290,7 +290,7 @@ def test_pack_transpose_batch_matches_single_launches():
             assert torch.equal(got[:, col0: col0 + width], ref[:, col0: col0 + width])
 
 
-@pytest.mark.parametrize("case", [(2, 56, 56), (3, 16, 24), (1, 8, 8), (40, 56, 56), (5, 24, 16)])
+@pytest.mark.parametrize("case", [(2, 56, 56), (3, 16, 24), (1, 8, 8), (40, 56, 56), (5, 24, 16), (3, 96, 96), (2, 12, 16), (70, 20, 40)])
 def test_conv3x3_c64_dma_patch_kernel(case):
     """8-wave persistent patch kernel with LDS-DMA patches (stage-1 forward / addend-free data gradient, bf16): output and BN partial
     statistics against ATen, forward weights and the flipped-transposed pack; (40, 56, 56) gives 280 blocks on the 256-workgroup
@@ -307,7 +307,9 @@ def test_conv3x3_c64_dma_patch_kernel(case):
     yr.backward(dy)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
     w_krsc = w.permute(0, 2, 3, 1).contiguous().to(DEV)
-    assert K.c64p_blocks(B, H, W) == min(B * H // 8, 256)
+    # 8 output rows per block where two 10 x (W+2) patches fit the LDS and H allows it, else 4 (the 96 x 96 maps of the stress shape)
+    rbp = 8 if (H % 8 == 0 and 2 * 10 * (W + 2) * 128 + 2048 <= 160 * 1024) else 4
+    assert K.c64p_blocks(B, H, W) == min(B * H // rbp, 256)
     y, stats, nb = K.conv3x3_c64p(nhwc(x), K.pack_rows(w_krsc.view(64, 576), dtype), B, H, W, want_stats=True)
     torch.cuda.synchronize()
     y_ref = yr.detach().permute(0, 2, 3, 1).reshape(-1, 64)
@@ -318,4 +320,29 @@ def test_conv3x3_c64_dma_patch_kernel(case):
     dx, _, _ = K.conv3x3_c64p(nhwc(dy), wflip, B, H, W)
     torch.cuda.synchronize()
     assert _relerr(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1).reshape(-1, 64)) < _tol(dtype)
-    assert K.c64p_blocks(2, 10, 10) == 0 and K.c64p_blocks(2, 12, 16) == 0          # unsupported shapes are refused, not mangled
+    assert K.c64p_blocks(2, 10, 10) == 0 and K.c64p_blocks(2, 6, 16) == 0 and K.c64p_blocks(2, 8, 128) == 0   # refused, not mangled
+
+
+@pytest.mark.parametrize("case", [(3, 96, 96), (2, 10, 16), (70, 20, 40), (2, 56, 56), (3, 12, 88)])
+def test_wgrad3x3_c64_row_block_variants(case):
+    """Stage-1 weight gradient on shapes the 4-rows-per-block 8-wave kernel does not take: 96 x 96 maps (the 384 x 384 stress
+    configuration: two rows per block so that both operands of two blocks fit the LDS), heights that are a multiple of 2 but not of
+    4, more row blocks than persistent workgroups.  Against torch's conv2d weight gradient on the bf16-rounded operands; += semantics;
+    bit-reproducible (per-workgroup slabs + fixed-order reduce)."""
+    K = sub("kernels")
+    B, H, W = case
+    assert K.c64w_blocks(B, H, W) > 0 and K.c64w_blocks(B, 7, 16) == 0 and K.c64w_blocks(B, 8, 12) == 0 and K.c64w_blocks(B, 12, 104) == 0
+    g = torch.Generator().manual_seed(B + H * 3 + W)
+    x = _round(torch.randn(B, 64, H, W, generator=g), torch.bfloat16)
+    dy = _round(torch.randn(B, 64, H, W, generator=g) * 0.1, torch.bfloat16)
+    ref = torch.nn.grad.conv2d_weight(x, (64, 64, 3, 3), dy, stride=1, padding=1).permute(0, 2, 3, 1).reshape(64, 576)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16)
+    xd, dyd = nhwc(x), nhwc(dy)
+    outs = []
+    for rep in range(2):
+        dw = torch.full((64, 576), 0.25, device=DEV)
+        K.wgrad3x3_c64(xd, dyd, dw, B, H, W)
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert _relerr(outs[0].cpu() - 0.25, ref) < 3e-3
+    assert torch.equal(outs[0], outs[1])

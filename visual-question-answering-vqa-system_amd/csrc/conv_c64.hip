@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(C64Params p) {
 //   * no vector-memory LOAD is issued by the computing waves besides the DMA (stores only), so nothing ever waits on the
 //     prefetch before the block-end barrier -- which is why the variant with an identity addend stays on the generic kernel.
 namespace {
-constexpr int RBP = 8;            // output rows per block
+// RBP = output rows per block: 8 where two (8+2) x (W+2) x 64 patches fit the 160 KB of LDS (W <= 62: the 56 x 56 maps of the default
+// configuration), 4 for wider maps (W <= 126: the 96 x 96 maps of the 384 x 384 stress configuration; 1.5x instead of 1.25x halo reads)
 typedef int i32x4_c64 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dma16_c64(i32x4_c64 rs, unsigned lds_addr, int voff, int soff) {
   lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
@@ -188,6 +189,7 @@ __device__ __forceinline__ void dma16_c64(i32x4_c64 rs, unsigned lds_addr, int v
 }
 }
 
+template <int RBP>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PWc = p.W + 2;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_c64_kernel(C64WgradParams p) {
 //     (col & 7) swizzle maps onto the same banks twice.
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr int RBW = 4;            // output rows per block
+// RBW = output rows per block: 4 where both operands of two blocks fit the LDS (W <= 62), 2 for wider maps (the 96 x 96 stress shape)
 __device__ __forceinline__ int swz16(int i) { return (i & 7) ^ (((i >> 3) & 1) << 2); }
 
 template <class F, int... I>
@@ -490,7 +492,7 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
 typedef __attribute__((ext_vector_type(2))) int i32x2_c64;
 typedef __attribute__((ext_vector_type(4))) int i32x4v_c64;
 
-template <int KH, int WC>                                      // WC: compile-time image width (address math folds), 0 = runtime
+template <int KH, int WC, int RBW>                             // WC: compile-time image width (address math folds), 0 = runtime
 __device__ __forceinline__ void wgrad_c64p_body(const C64WgradParams& p, char* smem, unsigned lds0) {
   typedef __attribute__((ext_vector_type(8))) short i16x8;
   const int Wd = WC ? WC : p.W;
@@ -685,16 +687,19 @@ __device__ __forceinline__ void wgrad_c64p_body(const C64WgradParams& p, char* s
 }
 }
 
+template <int RBW>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_c64p_kernel(C64WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
-  if (p.W == 56) {                                            // the model's stage-1 width: fully unrolled, constant addressing
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) wgrad_c64p_body<1, 56>(p, smem, lds0);  // waves 4-7
-    else wgrad_c64p_body<0, 56>(p, smem, lds0);                                                    // waves 0-3
-  } else {
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) wgrad_c64p_body<1, 0>(p, smem, lds0);
-    else wgrad_c64p_body<0, 0>(p, smem, lds0);
+  if constexpr (RBW == 4) {
+    if (p.W == 56) {                                          // the model's stage-1 width: fully unrolled, constant addressing
+      if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) wgrad_c64p_body<1, 56, 4>(p, smem, lds0);  // waves 4-7
+      else wgrad_c64p_body<0, 56, 4>(p, smem, lds0);                                                    // waves 0-3
+      return;
+    }
   }
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) wgrad_c64p_body<1, 0, RBW>(p, smem, lds0);
+  else wgrad_c64p_body<0, 0, RBW>(p, smem, lds0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,11 +905,17 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // persistent grid of the 8-wave LDS-DMA patch kernel (= rows of its statistics slab), 0 when the shape is unsupported
+static int c64p_rows(int H, int W) {         // output rows per block of the 8-wave patch kernel for this shape, 0: unsupported
+  for (int rbp = 8; rbp >= 4; rbp -= 4) {
+    const size_t shm = (size_t)2 * (rbp + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4;
+    if (H % rbp == 0 && (rbp * W) % 16 == 0 && shm <= 160 * 1024) return rbp;
+  }
+  return 0;
+}
 int vqa_conv3x3_c64p_blocks(int B, int H, int W) {
-  if (H % RBP || W % 8 || W > 126 || B <= 0) return 0;
-  const size_t shm = (size_t)2 * (RBP + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4;
-  if (shm > 160 * 1024) return 0;
-  const int nb = B * (H / RBP);
+  const int rbp = (W % 8 || W > 126 || B <= 0 || H <= 0) ? 0 : c64p_rows(H, W);
+  if (!rbp) return 0;
+  const int nb = B * (H / rbp);
   return nb < 256 ? nb : 256;
 }
 // forward / addend-free data gradient of the 64 -> 64 channel 3x3 conv with the 8-wave LDS-DMA patch kernel (no epilogue inputs)
@@ -919,10 +930,16 @@ int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int 
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb;
-  const size_t shm = (size_t)2 * (RBP + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4;
-  static size_t attr = 0;
-  if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
-  hipLaunchKernelGGL(conv3x3_c64p_kernel, dim3(grid), dim3(512), shm, st, p);
+  const int rbp = c64p_rows(H, W);
+  const size_t shm = (size_t)2 * (rbp + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4;
+  static size_t attr8 = 0, attr4 = 0;
+  if (rbp == 8) {
+    if (shm > attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64p_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr8 = shm; }
+    hipLaunchKernelGGL(conv3x3_c64p_kernel<8>, dim3(grid), dim3(512), shm, st, p);
+  } else {
+    if (shm > attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr4 = shm; }
+    hipLaunchKernelGGL(conv3x3_c64p_kernel<4>, dim3(grid), dim3(512), shm, st, p);
+  }
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // dw [64][576] fp32 (+=).  ws: scratch of >= vqa_conv3x3_c64_blocks(B,H,W) * 64*576 floats for the deterministic two-pass
@@ -950,28 +967,53 @@ int vqa_wgrad3x3_c128(const void* x, const void* dy, float* dw, int B, int H, in
   return VQA_OK;
 }
 
+// rows per block of the 8-wave LDS-DMA weight-gradient kernel for this shape (4 where both operands of two blocks fit the LDS, else 2), 0: not eligible
+static int c64wp_rows(int H, int W, size_t* shm_out) {
+  if (W % 8 || W > 126) return 0;
+  for (int r = 4; r >= 2; r -= 2) {
+    const size_t shm = (size_t)2 * ((size_t)(r + 2) * (W + 2) * 128 + (size_t)((r * W + 31) / 32 * 32) * 128);
+    if (H % r == 0 && shm <= 160 * 1024) { if (shm_out) *shm_out = shm; return r; }
+  }
+  return 0;
+}
+// slabs ([64][576] floats each) vqa_wgrad3x3_c64 needs in `ws` for this shape; 0: neither kernel takes it
+int vqa_wgrad3x3_c64_blocks(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  const int g4 = vqa_conv3x3_c64_blocks(B, H, W);
+  const int rbw = c64wp_rows(H, W, nullptr);
+  const int nblk = rbw ? B * (H / rbw) : 0, gp = nblk < 256 ? nblk : 256;
+  return g4 > gp ? g4 : gp;
+}
 int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t st) {
-  const int grid = vqa_conv3x3_c64_blocks(B, H, W);
-  if (!x || !dy || !dw || grid <= 0) return VQA_EARG;
+  const int grid = vqa_conv3x3_c64_blocks(B, H, W);            // the 4-wave kernel's persistent grid (0: it does not take the shape)
+  size_t shm_p = 0;
+  const int rbw = c64wp_rows(H, W, &shm_p);
+  const int nblk_p = rbw ? B * (H / rbw) : 0, grid_p = nblk_p < 256 ? nblk_p : 256;
+  if (!x || !dy || !dw || (grid <= 0 && grid_p <= 0)) return VQA_EARG;
   C64WgradParams p;
   p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.B = B; p.H = H; p.W = W;
   const int dbg_env = vqa_env_int("VQA_C64WP_DBG", 0);
   p.dbg = dbg_env;
-  p.ws = (ws && ws_floats >= (long long)grid * 64 * 576) ? ws : nullptr;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)xb;
   // 8-wave LDS-DMA form (needs the slab workspace: it has no atomic flush); VQA_C64WP=0 keeps the 4-wave kernel (measurement)
   const int wp_env = vqa_env_int("VQA_C64WP", 1);
-  const size_t shm_p = (size_t)2 * ((size_t)(RBW + 2) * (W + 2) * 128 + (size_t)((RBW * W + 31) / 32 * 32) * 128);
-  const int nblk_p = B * (H / RBW), grid_p = nblk_p < 256 ? nblk_p : 256;
-  if (wp_env && p.ws && H % RBW == 0 && W % 8 == 0 && shm_p <= 160 * 1024 && grid_p <= grid) {
-    static size_t attr_p = 0;
-    if (shm_p > attr_p) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_c64p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_p); attr_p = shm_p; }
-    hipLaunchKernelGGL(wgrad3x3_c64p_kernel, dim3(grid_p), dim3(512), shm_p, st, p);
+  if (wp_env && ws && grid_p > 0 && ws_floats >= (long long)grid_p * 64 * 576) {
+    p.ws = ws;
+    static size_t attr4 = 0, attr2 = 0;
+    if (rbw == 4) {
+      if (shm_p > attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_c64p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_p); attr4 = shm_p; }
+      hipLaunchKernelGGL(wgrad3x3_c64p_kernel<4>, dim3(grid_p), dim3(512), shm_p, st, p);
+    } else {
+      if (shm_p > attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_c64p_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_p); attr2 = shm_p; }
+      hipLaunchKernelGGL(wgrad3x3_c64p_kernel<2>, dim3(grid_p), dim3(512), shm_p, st, p);
+    }
     VQA_LAUNCH_CHECK();
     return vqa_slab_reduce(p.ws, dw, grid_p, 64 * 576, st);
   }
+  if (grid <= 0) return VQA_EARG;
+  p.ws = (ws && ws_floats >= (long long)grid * 64 * 576) ? ws : nullptr;
   const int MP = (RBG * W + 31) / 32 * 32;
   const size_t shm = (size_t)(RBG + 2) * (W + 2) * CH * 2 + (size_t)MP * (CH + 4) * 2;
   static size_t attr = 0;

@@ -259,7 +259,8 @@ class HipEngine:
     def _c64_ok(self, B, H, W, Cin, Cout, R, stride, wgrad=False):
         if not wgrad and not self.use_c64_fwd:
             return False          # since the LDS-DMA rewrite the generic implicit GEMM is as fast for forward / data gradient
-        return (self.dtype == torch.bfloat16 and Cin == 64 and Cout == 64 and R == 3 and stride == 1 and K.c64_blocks(B, H, W) > 0)
+        ok = self.dtype == torch.bfloat16 and Cin == 64 and Cout == 64 and R == 3 and stride == 1
+        return ok and (K.c64w_blocks(B, H, W) if wgrad else K.c64_blocks(B, H, W)) > 0
 
     def _c128w_ok(self, B, H, W, Cin, Cout, stride):
         """128 -> 128 channel 3x3/1 conv on 28 x 28 maps (stage 2): the 8-wave LDS-DMA weight-gradient kernel."""

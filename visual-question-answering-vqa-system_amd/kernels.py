@@ -163,11 +163,16 @@ def conv3x3_c64p(x, w, B, H, W, *, want_stats=False, stats_acc=None):
     return out, stats, nb
 
 
+def c64w_blocks(B, H, W) -> int:
+    """Slabs vqa_wgrad3x3_c64 wants (8-wave LDS-DMA kernel: 4 or 2 rows per block; else the 4-wave kernel); 0: unsupported shape."""
+    return L.count("vqa_wgrad3x3_c64_blocks", B, H, W)
+
+
 def wgrad3x3_c64(x, dy, dw, B, H, W):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    wsf = c64_blocks(B, H, W) * 64 * 576                      # one partial dW per persistent workgroup, reduced in a fixed order
+    wsf = c64w_blocks(B, H, W) * 64 * 576                     # one partial dW per persistent workgroup, reduced in a fixed order
     ws = torch.empty(wsf, device=x.device, dtype=torch.float32)
     call("vqa_wgrad3x3_c64", ptr(x), ptr(dy), ptr(dw), B, H, W, ptr(ws), wsf)
     if PROFILE is not None:
