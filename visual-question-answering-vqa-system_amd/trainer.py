@@ -20,7 +20,7 @@ from ._lib import call, dt, ptr
 
 # Gradient segments (layout.bucket_ranges, reported by engine.backward in this order: answer_head, fusion, text_encoder, stage4 ...
 # stem) are all-reduced in FOUR collectives: adjacent segments that finish close together travel as one message.
-#   * head + fusion + text encoder (29.6 MB): the first two finish inside the latency-bound fusion chain right after the forward
+#   * head + fusion + text encoder (32.4 MB): the first two finish inside the latency-bound fusion chain right after the forward
 #     (~120 dependent launches of 4-40 us).  Issuing a collective there costs host time exactly where the GPU is waiting for the
 #     next launch (measured with a one-rank RCCL group at B=512: 9 collectives, three of them inside the chain: +0.9 ms per step);
 #     merged, the message leaves when the text encoder's backward (side stream) reports, while the stage-4 convolutions run;
@@ -39,7 +39,7 @@ class GradBucketReducer:
     def __init__(self, flat_grad: torch.Tensor, buckets, process_group=None, overlap=True, force=False, avoid_streams=()):
         """force: run the whole bucket choreography (communication stream, events, async all-reduce per bucket, waits) even in a
         world of ONE rank -- a single-rank RCCL group executes the same code path an 8-GPU job does, so the one-GPU test box can
-        run it for real (tests/test_gpu_nccl_world1.py, bench.py --force-reducer); needs an initialised process group."""
+        run it for real (tests/test_gpu_bench_ranks.py, bench.py --force-reducer); needs an initialised process group."""
         self.G = flat_grad
         self.buckets = list(buckets)
         self._range = {name: (lo, hi) for name, lo, hi in self.buckets}
