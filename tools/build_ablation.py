@@ -6,6 +6,7 @@ environment.  Usage from a tool:
     import tools.build_ablation as A; A.use()      # before the first kernel call: builds if stale, points _lib at the copy
 """
 import importlib
+import importlib.util
 import os
 import subprocess
 import sys

@@ -15,6 +15,8 @@ tr = pkg.trainer.HipTrainer(model)
 eng = tr.engine
 images, ids, mask, answers = bench.synth_batch(B, torch.device("cuda", 0), 1234)
 maskf = mask.float()
+if len(sys.argv) > 2 and sys.argv[2] == "serial":
+    eng.two_streams = False
 for _ in range(8):
     tr.step(images, ids, mask, answers)
 torch.cuda.synchronize()
@@ -27,8 +29,10 @@ for it in range(N):
         e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((name, e))
     G.zero_()
     mark("start")
+    eng.mark = mark
     logits, _, tape = eng.forward(images, ids, maskf, True, False, need_tape=True)
-    mark("forward (stem .. logits)")
+    eng.mark = None
+    mark("forward: head")
     dl = torch.empty_like(logits); loss = torch.zeros(1, device="cuda"); ws = torch.empty(B, device="cuda")
     L.call("vqa_cross_entropy", 0, logits.data_ptr(), answers.data_ptr(), loss.data_ptr(), dl.data_ptr(), None, B, logits.shape[1], 1.0, None, ws.data_ptr())
     main = torch.cuda.current_stream()
@@ -45,3 +49,5 @@ for it in range(N):
     acc["TOTAL"] += marks[0][1].elapsed_time(marks[-1][1])
 for k, v in acc.items():
     print(f"{k:40s} {v / N:8.3f} ms")
+if len(sys.argv) > 2 and sys.argv[2] == "serial":
+    sys.exit(0)

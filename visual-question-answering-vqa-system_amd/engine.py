@@ -112,6 +112,7 @@ class HipEngine:
         # test hook (tests/test_gpu_insitu.py): a dict here receives, per residual block, the intermediate gradients of its backward
         # (dout, dy2, dyd, da1, dy1, dx) so that every layer of a LIVE full-size bf16 step can be checked locally against fp32 math
         self.capture = None
+        self.mark = None                          # measurement hook (tools/phase_times.py): called with a label at forward boundaries
 
     # ------------------------------------------------------------------ parameter access
     def P(self, name):                       # fp32 master, flat 1-D
@@ -517,6 +518,7 @@ class HipEngine:
         call("vqa_stem_pool_fwd", dt(T), ptr(y), ptr(coef), ptr(x), ptr(idx), B, H1, W1, 64)
         tape["stem"] = dict(images=images, y=y, coef=coef, idx=idx, geom=sgeom, H1=H1, W1=W1)
         H, W, C = Hp, Wp, 64
+        if self.mark: self.mark("forward: stem")
 
         # ---- residual stages, A2-A5
         folded = self._fold_bn() if (self.fold_eval and not training and not need_tape) else None
@@ -604,6 +606,7 @@ class HipEngine:
                 srec["spatial"] = dict(x=x, pooled2=pooled2, amax=amax, amap=amap, H=H, W=W, C=C)
                 x = out
             tape["stages"].append(srec)
+            if self.mark: self.mark(f"forward: stage{s}")
         feat = x                                  # [B*Hf*Wf, 512] == tokens of the projector (NHWC makes the permute free)
         Hf, Wf, Cf = H, W, C
         ntok = Hf * Wf
@@ -643,6 +646,7 @@ class HipEngine:
             call("vqa_add", dt(T), ptr(att), ptr(txt), ptr(fused_pre), Bt * d)
         fused, fst = self._ln(fused_pre, "fusion.output_norm")
         tape["pool"] = dict(q=q, enc=enc, cat=cat, z=z, fused_pre=fused_pre, fst=fst, maskf=maskf, L=L, d=d)
+        if self.mark: self.mark("forward: fusion")
 
         # ---- answer head, A12
         c = "answer_head.classifier"
