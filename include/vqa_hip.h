@@ -245,7 +245,7 @@ int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float l
 /* ---- input pipeline on the GPU -----------------------------------------------------------------
  * vqa_image_normalize: torchvision ToTensor + Normalize of data/preprocess.py:34-35,117-121 -- uint8 HWC [B][H][W][3] ->
  * float32 NCHW, (u/255 - mean[c]) / std[c] in torch's operation order (bit-identical), optional per-sample horizontal flip
- * (flip[b] != 0; RandomHorizontalFlip, data/preprocess.py:73).  W % 4 == 0.  ColorJitter (PIL) stays on the host.
+ * (flip[b] != 0; RandomHorizontalFlip, data/preprocess.py:73).  W % 4 == 0.
  * vqa_pack_tokens: Tokenizer.encode (utils/tokenizer.py:196-250) for a batch -- ragged vocabulary indices words[offsets[b] ..
  * offsets[b+1]) -> ids / mask int64 [B][L]: START + words + END, truncated to L with END forced onto the last slot, PAD after. */
 /* vqa_image_resize: transforms.Resize((RH, RW)) of a PIL image (data/preprocess.py:70,90,118; api/inference.py:140-170), i.e.
@@ -260,6 +260,18 @@ long long vqa_image_resize_ws(int n, const int* H, const int* W, int RH, int RW,
 int vqa_image_resize(const uint8_t* in, const long long* in_off, const int* H, const int* W, const int* crop_yx, int n, int RH, int RW,
                      int OH, int OW, uint8_t* out_u8, float* out_nchw, const uint8_t* flip, float mean0, float mean1, float mean2,
                      float std0, float std1, float std2, void* ws, long long ws_bytes, hipStream_t stream);
+/* vqa_image_color_jitter: transforms.ColorJitter (data/preprocess.py:77-82) of uint8 HWC images [B][H][W][3], fused with ToTensor +
+ * Normalize.  On PIL images torchvision's adjustments are Pillow code -- ImageEnhance.Brightness / Contrast / Color =
+ * Image.blend(black | rounded mean of the L band | L band, image, factor), hue = RGB -> HSV, H += delta (uint8 wrap), HSV -> RGB --
+ * restated bit-exactly (libImaging Blend.c, Convert.c rgb2l / rgb2hsv_row / hsv2rgb: same float / double mix, no FMA contraction).
+ * order: device uint8 [B][4], the permutation ColorJitter.forward draws (0 brightness, 1 contrast, 2 saturation, 3 hue; other values
+ * are skipped).  factors: device float [B][4] = brightness, contrast, saturation factor and the hue DELTA int(hue_factor * 255) mod 256
+ * as a float (the caller computes it in double, as torchvision does); NaN switches that adjustment off.  Outputs (either may be
+ * NULL): out_u8 [B][H][W][3] (what PIL returns) and out_nchw float32 [B][3][H][W] = ToTensor + Normalize of it.
+ * sums: device scratch of B 64-bit words (the L-band sums the contrast step needs; zeroed inside). */
+int vqa_image_color_jitter(const uint8_t* in_hwc, const uint8_t* order, const float* factors, int B, int H, int W, uint8_t* out_u8,
+                           float* out_nchw, float mean0, float mean1, float mean2, float std0, float std1, float std2,
+                           unsigned long long* sums, hipStream_t stream);
 int vqa_image_normalize(const uint8_t* in_hwc, float* out_nchw, const uint8_t* flip, int B, int H, int W, float mean0, float mean1,
                         float mean2, float std0, float std1, float std2, hipStream_t stream);
 int vqa_pack_tokens(const int* words, const long long* offsets, long long* ids, long long* mask, int B, int L, int add_special,

@@ -230,7 +230,43 @@ def gen_resize():
     print("resize_pil", len(IO.RESIZE_CASES), "cases", os.path.getsize(os.path.join(OUT, "resize_pil.npz")), "bytes")
 
 
+def pil_color_jitter(img, order, brightness, contrast, saturation, hue):
+    """torchvision's ColorJitter.forward on a PIL image, spelled with the PIL calls its functional_pil ops make (torchvision is absent)."""
+    from PIL import Image, ImageEnhance
+    im = Image.fromarray(img, mode="RGB")
+    for fn in order:
+        if fn == 0 and brightness is not None:
+            im = ImageEnhance.Brightness(im).enhance(brightness)                  # F.adjust_brightness
+        elif fn == 1 and contrast is not None:
+            im = ImageEnhance.Contrast(im).enhance(contrast)                      # F.adjust_contrast
+        elif fn == 2 and saturation is not None:
+            im = ImageEnhance.Color(im).enhance(saturation)                       # F.adjust_saturation
+        elif fn == 3 and hue is not None:                                         # F.adjust_hue
+            h, s_, v = im.convert("HSV").split()
+            np_h = np.array(h, dtype=np.uint8)
+            with np.errstate(over="ignore", invalid="ignore"):
+                np_h += np.array(hue * 255).astype(np.uint8)                      # uint8 addition wraps across the hue circle
+            im = Image.merge("HSV", (Image.fromarray(np_h, "L"), s_, v)).convert("RGB")
+    return np.array(im, copy=True)
+
+
+def gen_jitter():
+    """transforms.ColorJitter (data/preprocess.py:77-82) on PIL images = PIL's ImageEnhance / HSV conversion: outputs of the REAL PIL
+    for fixed permutations and factors on rebuilt integer-pattern images (oracle.input_oracle.JITTER_CASES)."""
+    import warnings
+    from oracle import input_oracle as IO
+    out = {"pil_version": np.array(__import__("PIL").__version__)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, H, W, seed, nb, order, b, c, s_, h in IO.JITTER_CASES:
+            out[f"{tag}_u8"] = pil_color_jitter(IO.pattern_image(H, W, seed, nb), order, b, c, s_, h)
+    np.savez_compressed(os.path.join(OUT, "jitter_pil.npz"), **out)
+    print("jitter_pil", len(IO.JITTER_CASES), "cases", os.path.getsize(os.path.join(OUT, "jitter_pil.npz")), "bytes")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "jitter":
+        gen_jitter(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "resize":
         gen_resize(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
@@ -245,3 +281,4 @@ if __name__ == "__main__":
     gen_metrics()
     gen_input()
     gen_resize()
+    gen_jitter()

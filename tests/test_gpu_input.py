@@ -2,6 +2,8 @@
   vqa_pack_tokens      == the REAL reference Tokenizer's batch_encode (golden fixture), bit-exact (index work)
   vqa_image_normalize  == ToTensor + Normalize restated with torch (oracle.input_oracle), bit-exact, at 224x224 and with flips
   vqa_image_resize     == PIL.Image.resize(BILINEAR) + ToTensor + Normalize, pinned by outputs of the REAL PIL (resize_pil.npz)
+  vqa_image_color_jitter == PIL ImageEnhance blends + HSV hue shift (what ColorJitter runs on PIL images), pinned by the REAL PIL
+                          (jitter_pil.npz) and, over all 2^24 colours, by the oracle that tests/test_input_cpu.py pins to PIL
 and the drop-in surfaces built on them (Tokenizer.batch_encode_device, DeviceImageNormalizer, gpu_collate_fn) feeding the model."""
 import json
 import os
@@ -163,3 +165,95 @@ def test_device_resize_ragged_batch_matches_oracle_and_feeds_the_model():
     assert batch["images"].shape == (3, 3, 224, 224) and batch["images"].is_cuda
     ref3 = IO.to_tensor_normalize(torch.from_numpy(np.stack([IO.pil_resize_bilinear(imgs[i], 224, 224) for i in range(3)])))
     assert torch.equal(batch["images"].cpu(), ref3)
+
+
+# ---- transforms.ColorJitter (data/preprocess.py:77-82) ---------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def jgold(golden_dir):
+    return np.load(os.path.join(golden_dir, "jitter_pil.npz"))
+
+
+def _factors(b, c, s, h):
+    return torch.tensor([[float("nan") if v is None else v for v in (b, c, s, h)]], dtype=torch.float64)
+
+
+@pytest.mark.parametrize("case", IO.JITTER_CASES, ids=[c[0] for c in IO.JITTER_CASES])
+def test_device_color_jitter_bit_exact_against_pil(jgold, case):
+    """uint8 output == what the real PIL's ImageEnhance / HSV round trip produced (golden), float output == ToTensor + Normalize of it."""
+    tag, H, W, seed, nb, order, b, c, s, h = case
+    P = pkg().load_dropin_preprocess()
+    img = torch.from_numpy(IO.pattern_image(H, W, seed, nb))[None].to(DEV)
+    cj = P.DeviceColorJitter(0.2, 0.2, 0.2, 0.1)
+    out, u8 = cj(img, order=torch.tensor([order]), factors=_factors(b, c, s, h), return_u8=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(u8[0].cpu().numpy(), jgold[f"{tag}_u8"])
+    assert torch.equal(out.cpu(), IO.to_tensor_normalize(torch.from_numpy(jgold[f"{tag}_u8"])[None]))
+
+
+def test_device_hue_round_trip_on_every_colour():
+    """RGB -> HSV -> (+delta) -> RGB for all 2^24 colours (a 4096 x 4096 image) at three shifts, and the saturation / brightness blends
+    on the same image, against the numpy restatement that tests/test_input_cpu.py pins to the real PIL over the same full domain."""
+    P = pkg().load_dropin_preprocess()
+    allc = np.stack(np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij"), -1).reshape(1, 4096, 4096, 3).astype(np.uint8)
+    x = torch.from_numpy(allc).to(DEV)
+    cj = P.DeviceColorJitter(0.2, 0.2, 0.2, 0.5)
+    for hue in (0.0, 0.1, -0.37):
+        _, u8 = cj(x, order=torch.tensor([[3, 0, 1, 2]]), factors=_factors(None, None, None, hue), return_u8=True)
+        assert np.array_equal(u8[0].cpu().numpy(), IO.color_jitter(allc[0], (3,), hue=hue)), hue
+    for sat, br in ((0.8, 1.2), (1.37, 0.61)):
+        _, u8 = cj(x, order=torch.tensor([[2, 0, 3, 1]]), factors=_factors(br, None, sat, None), return_u8=True)
+        assert np.array_equal(u8[0].cpu().numpy(), IO.color_jitter(allc[0], (2, 0), brightness=br, saturation=sat)), (sat, br)
+
+
+def test_device_color_jitter_batch_random_draws_and_training_pipeline():
+    """A batch with per-image permutations and factors drawn by the class itself (every image against the oracle), then the whole
+    training transform of data/preprocess.py:66-87 -- Resize(256) -> RandomCrop(224) -> flip -> ColorJitter -> ToTensor -> Normalize --
+    in one resizer call on a ragged batch, and through gpu_collate_fn."""
+    P = pkg().load_dropin_preprocess()
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 37, 96, 120
+    imgs = np.stack([IO.pattern_image(H, W, 300 + i, 8 if i % 2 else 5) for i in range(B)])
+    cj = P.DeviceColorJitter(brightness=0.2, contrast=0.2, saturation=0.2, hue=0.1)
+    order, factors = cj.draw(B, g)
+    assert order.shape == (B, 4) and sorted(order[0].tolist()) == [0, 1, 2, 3] and len({tuple(o.tolist()) for o in order}) > 5
+    assert float(factors[:, :3].min()) >= 0.8 and float(factors[:, :3].max()) <= 1.2 and float(factors[:, 3].abs().max()) <= 0.1
+    out, u8 = cj(torch.from_numpy(imgs).to(DEV), order=order, factors=factors, return_u8=True)
+    torch.cuda.synchronize()
+    got = u8.cpu().numpy()
+    for i in range(B):
+        f = [float(v) for v in factors[i]]
+        ref = IO.color_jitter(imgs[i], order[i].tolist(), *[np.float32(v) if k < 3 else v for k, v in enumerate(f)])
+        assert np.array_equal(got[i], ref), (i, order[i].tolist(), f)
+    assert torch.equal(out.cpu(), IO.to_tensor_normalize(torch.from_numpy(got)))
+    # adjustments switched off: an identity that still normalises; contrast only: needs the image mean
+    off = P.DeviceColorJitter()
+    assert off.brightness is None and off.hue is None
+    o2, u2 = off(torch.from_numpy(imgs[:3]).to(DEV), return_u8=True)
+    assert np.array_equal(u2.cpu().numpy(), imgs[:3])
+    with pytest.raises(ValueError):
+        P.DeviceColorJitter(hue=0.6)
+    with pytest.raises(ValueError):
+        cj(torch.from_numpy(imgs[:1]).to(DEV), order=order[:1], factors=torch.tensor([[1.0, 1.0, 1.0, 0.7]]))
+    with pytest.raises(RuntimeError):
+        cj(torch.from_numpy(imgs[:2]).to(DEV), order=order[:1], factors=factors[:1])
+    with pytest.raises(RuntimeError):
+        cj(torch.from_numpy(imgs[:1]))                                  # GPU only
+    # the whole augmented pipeline on a ragged batch
+    rng = np.random.default_rng(9)
+    raw = [IO.pattern_image(int(rng.integers(40, 300)), int(rng.integers(40, 300)), 500 + i, 5) for i in range(6)]
+    yx = [(int(rng.integers(0, 33)), int(rng.integers(0, 33))) for _ in raw]
+    flip = torch.tensor([i % 2 == 0 for i in range(6)])
+    rz = P.DeviceImageResizer(size=256, crop=224, jitter=cj)
+    order, factors = cj.draw(6, g)
+    out, u8 = rz(raw, crop_yx=yx, flip=flip, return_u8=True, jitter_params=(order, factors))
+    for i in range(6):
+        ref = IO.pil_resize_bilinear(raw[i], 256, 256)[yx[i][0]: yx[i][0] + 224, yx[i][1]: yx[i][1] + 224]
+        if flip[i]:
+            ref = ref[:, ::-1]
+        f = [float(v) for v in factors[i]]
+        ref = IO.color_jitter(np.ascontiguousarray(ref), order[i].tolist(), *f)
+        assert np.array_equal(u8[i].cpu().numpy(), ref), i
+    assert torch.equal(out.cpu(), IO.to_tensor_normalize(u8.cpu()))
+    items = [(raw[i], torch.zeros(20, dtype=torch.long), torch.ones(20, dtype=torch.long), i) for i in range(4)]
+    batch = P.gpu_collate_fn(items, resizer=rz, flip_p=0.5, generator=torch.Generator().manual_seed(3))
+    assert batch["images"].shape == (4, 3, 224, 224) and torch.isfinite(batch["images"]).all()

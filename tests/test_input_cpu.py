@@ -107,3 +107,42 @@ def test_pil_coefficients_known_answers():
     assert abs(int(kk[0].sum()) - one) <= 2 and abs(int(kk[3].sum()) - one) <= 2
     xmin, xn, kk = IO.pil_bilinear_coeffs(5, 5)
     assert all(int(kk[i, : xn[i]].max()) == one and int(kk[i].sum()) == one for i in range(5))
+
+
+# ---- transforms.ColorJitter = PIL ImageEnhance + HSV conversion (data/preprocess.py:77-82): oracle pinned by the real PIL ----------------
+@pytest.fixture(scope="module")
+def jgold(golden_dir):
+    return np.load(os.path.join(golden_dir, "jitter_pil.npz"))
+
+
+@pytest.mark.parametrize("case", IO.JITTER_CASES, ids=[c[0] for c in IO.JITTER_CASES])
+def test_oracle_color_jitter_is_bit_exact_against_pil(jgold, case):
+    tag, H, W, seed, nb, order, b, c, s, h = case
+    got = IO.color_jitter(IO.pattern_image(H, W, seed, nb), order, b, c, s, h)
+    assert got.dtype == np.uint8 and np.array_equal(got, jgold[f"{tag}_u8"])
+
+
+def _all_colours():
+    return np.stack(np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij"), -1).reshape(4096, 4096, 3).astype(np.uint8)
+
+
+def test_oracle_colour_conversions_match_pil_on_every_input():
+    """RGB -> L, RGB -> HSV and HSV -> RGB of the installed PIL over all 2^24 triples (an exhaustive pin: the domain is finite), and
+    Image.blend over every (degenerate, image) byte pair for factors inside, outside and at the ends of [0, 1]."""
+    Image = pytest.importorskip("PIL.Image")
+    allc = _all_colours()
+    assert np.array_equal(IO.pil_rgb_to_l(allc), np.asarray(Image.fromarray(allc, "RGB").convert("L")))
+    assert np.array_equal(IO.pil_rgb_to_hsv(allc), np.asarray(Image.fromarray(allc, "RGB").convert("HSV")))
+    assert np.array_equal(IO.pil_hsv_to_rgb(allc), np.asarray(Image.fromarray(allc, "HSV").convert("RGB")))
+    a, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    ia, ib = Image.fromarray(a, "L"), Image.fromarray(b, "L")
+    rng = np.random.default_rng(5)
+    for f in [0.0, 1.0, 0.8, 1.2, 0.5, 1.9999, 2.5, -0.3, 1e-3] + list(rng.uniform(0.0, 2.0, 40)):
+        assert np.array_equal(IO.pil_blend(a, b, f), np.asarray(Image.blend(ia, ib, f))), f
+
+
+def test_hue_delta_wraps_like_a_uint8_addition():
+    assert IO.hue_delta(0.1) == 25 and IO.hue_delta(-0.1) == 231 and IO.hue_delta(0.5) == 127 and IO.hue_delta(-0.5) == 129
+    assert IO.hue_delta(0.0) == 0 and IO.hue_delta(-0.001) == 0
+    with pytest.raises(ValueError):
+        IO.color_jitter(np.zeros((2, 2, 3), np.uint8), (3,), hue=0.6)

@@ -26,6 +26,36 @@ for B in (64, 512):
     t = e0.elapsed_time(e1) / 20 * 1e-3
     nbytes = img.numel() * (1 + 4)
     print(f"image_normalize B={B}: {t*1e6:8.1f} us  {nbytes/t/1e12:5.2f} TB/s (u8 in + f32 out = {nbytes/1e6:.0f} MB)  {B/t/1e6:.2f} M images/s")
+cj = P.DeviceColorJitter(0.2, 0.2, 0.2, 0.1)
+for B in (64, 512):
+    img = torch.randint(0, 256, (B, 224, 224, 3), dtype=torch.uint8, device=dev)
+    order, factors = cj.draw(B, torch.Generator().manual_seed(1))
+    for _ in range(3):
+        cj(img, order=order, factors=factors)
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        cj(img, order=order, factors=factors)
+    e1.record(); torch.cuda.synchronize()
+    t, th = e0.elapsed_time(e1) / 20 * 1e-3, (time.perf_counter() - h0) / 20
+    print(f"color_jitter B={B}: {t*1e6:8.1f} us on the device ({B/t/1e6:.2f} M images/s), {th*1e6:.0f} us wall per call with the parameter upload")
+# the whole training transform on a ragged batch of decoded images (host arrays, 300-640 px): upload + resize + crop + flip + jitter
+import numpy as np
+rng = np.random.default_rng(0)
+raw = [rng.integers(0, 256, (int(rng.integers(300, 480)), int(rng.integers(400, 640)), 3), dtype=np.uint8) for _ in range(128)]
+aug = P.DeviceImageResizer(size=256, crop=224, jitter=cj)
+yx = [(3, 5)] * len(raw); fl = torch.zeros(len(raw), dtype=torch.bool)
+for _ in range(2):
+    aug(raw, crop_yx=yx, flip=fl)
+torch.cuda.synchronize()
+h0 = time.perf_counter()
+for _ in range(5):
+    aug(raw, crop_yx=yx, flip=fl)
+torch.cuda.synchronize()
+th = (time.perf_counter() - h0) / 5
+print(f"training transform, 128 decoded images of 300-480 x 400-640 from host memory: {th*1e3:.1f} ms per batch = {len(raw)/th/1e3:.1f} k images/s (upload included)")
 tok = T.Tokenizer(max_length=20, vocab_size=10000)
 words = [f"w{i}" for i in range(5000)]
 import random

@@ -91,6 +91,7 @@ SIGNATURES = {
     "vqa_convert": [I, I, P, P, LL, P],
     "vqa_sumsq": [P, LL, P, P],
     "vqa_image_normalize": [P, P, P, I, I, I, F, F, F, F, F, F, P],
+    "vqa_image_color_jitter": [P, P, P, I, I, I, P, P, F, F, F, F, F, F, P, P],
     "vqa_image_resize_ws": [I, P, P, I, I, I],
     "vqa_image_resize": [P, P, P, P, P, I, I, I, I, I, P, P, P, F, F, F, F, F, F, P, LL, P],
     "vqa_pack_tokens": [P, P, P, P, I, I, I, I, I, I, P],

@@ -1,12 +1,13 @@
 // Input pipeline on the GPU: the two steps either side of the host decode.
 //   vqa_image_normalize : uint8 HWC image batch -> float32 NCHW, ToTensor + Normalize (data/preprocess.py:34-35,117-121:
 //                         x/255, then (x - mean[c]) / std[c]) with an optional per-sample horizontal flip
-//                         (RandomHorizontalFlip of data/preprocess.py:73).  The PIL Resize / ColorJitter in front of it stay on the host.
+//                         (RandomHorizontalFlip of data/preprocess.py:73).
 //   vqa_pack_tokens     : ragged word-index lists -> padded token ids + attention mask with the START / END / truncation /
 //                         padding conventions of Tokenizer.encode (utils/tokenizer.py:196-250); the string work (lower-casing,
 //                         regex split, dictionary lookup) stays on the host.
 //   vqa_image_resize    : transforms.Resize (= PIL.Image.resize BILINEAR, bit-exact) [+ RandomCrop window + flip] fused with
 //                         ToTensor + Normalize for a ragged batch of decoded images (see below).
+//   vqa_image_color_jitter : transforms.ColorJitter (= PIL ImageEnhance blends + HSV hue shift, bit-exact) fused with ToTensor + Normalize.
 // All are pure byte / index movers: HBM-bound.
 #include "common.h"
 
@@ -206,6 +207,128 @@ __global__ __launch_bounds__(256) void resize_v_kernel(ResizeGroup g, const uint
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// transforms.ColorJitter(brightness, contrast, saturation, hue) on a PIL image (data/preprocess.py:77-82) is Pillow code (third
+// party; 12.2.0 pinned by this image): ImageEnhance.Brightness / Contrast / Color = Image.blend(degenerate, image, factor) with the
+// degenerate image black / the rounded mean of the L band / the L band, and the hue shift = RGB -> HSV, H += delta (uint8
+// wrap-around), HSV -> RGB.  libImaging's Blend.c (float, truncation inside [0, 1], clip outside), Convert.c rgb2l (16.16 fixed
+// point), rgb2hsv_row and hsv2rgb (float / double mix of the C source: double literals, float variables, round()) are restated with
+// the same operation order and no FMA contraction, so every uint8 is bit-identical to PIL: tests/golden/jitter_pil.npz (real PIL),
+// and the oracle restatement the GPU tests compare with is pinned over all 2^24 colours (tests/test_input_cpu.py).
+// Contrast needs the mean of the whole image AFTER the adjustments that precede it in the image's permutation: pass 1 re-applies
+// those per pixel and adds the L values into one 64-bit integer per image, pass 2 applies everything and normalises.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int jit_l(const int (&px)[3]) { return (px[0] * 19595 + px[1] * 38470 + px[2] * 7471 + 0x8000) >> 16; }
+
+__device__ __forceinline__ int jit_blend(int a, int b, float alpha) {     // a: degenerate, b: image
+#pragma clang fp contract(off)
+  if (alpha == 0.0f) return a;
+  if (alpha == 1.0f) return b;
+  const float prod = alpha * (float)(b - a);
+  const float t = (float)a + prod;
+  if (alpha >= 0.0f && alpha <= 1.0f) return (int)t & 255;
+  return t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (int)t);
+}
+
+__device__ __forceinline__ void jit_hue(int (&px)[3], int delta) {
+#pragma clang fp contract(off)
+  const int r = px[0], g = px[1], b = px[2];
+  const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+  int uh = 0, us = 0;
+  const int uv = maxc;
+  if (minc != maxc) {
+    const float cr = (float)(maxc - minc);
+    const float s = __fdiv_rn(cr, (float)maxc);
+    const float rc = __fdiv_rn((float)(maxc - r), cr), gc = __fdiv_rn((float)(maxc - g), cr), bc = __fdiv_rn((float)(maxc - b), cr);
+    float h;
+    if (r == maxc) h = bc - gc;
+    else if (g == maxc) h = (float)((2.0 + (double)rc) - (double)bc);
+    else h = (float)((4.0 + (double)gc) - (double)rc);
+    h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+    uh = (int)((double)h * 255.0); uh = uh < 0 ? 0 : (uh > 255 ? 255 : uh);
+    us = (int)((double)s * 255.0); us = us < 0 ? 0 : (us > 255 ? 255 : us);
+  }
+  uh = (uh + delta) & 255;
+  if (us == 0) { px[0] = px[1] = px[2] = uv; return; }
+  const double hf = (double)uh * 6.0 / 255.0;
+  const double fl = floor(hf);
+  const double f = (double)(float)(hf - fl);
+  const double fs = (double)(float)((double)us / 255.0);
+  const double v = (double)uv;
+  const double one_m = 1.0 - f;
+  int p = (int)round(v * (1.0 - fs)), q = (int)round(v * (1.0 - fs * f)), t = (int)round(v * (1.0 - fs * one_m));
+  p = p < 0 ? 0 : (p > 255 ? 255 : p); q = q < 0 ? 0 : (q > 255 ? 255 : q); t = t < 0 ? 0 : (t > 255 ? 255 : t);
+  switch ((int)fl % 6) {
+    case 0: px[0] = uv; px[1] = t; px[2] = p; break;
+    case 1: px[0] = q; px[1] = uv; px[2] = p; break;
+    case 2: px[0] = p; px[1] = uv; px[2] = t; break;
+    case 3: px[0] = p; px[1] = q; px[2] = uv; break;
+    case 4: px[0] = t; px[1] = p; px[2] = uv; break;
+    default: px[0] = uv; px[1] = p; px[2] = q; break;
+  }
+}
+
+// FINAL = false: adjustments in front of the contrast step, then the L value into sums[b].  FINAL = true: all four, then the outputs.
+template <bool FINAL>
+__global__ __launch_bounds__(256) void color_jitter_kernel(const uint8_t* __restrict__ in, const uint8_t* __restrict__ order,
+                                                           const float* __restrict__ factors, unsigned long long* __restrict__ sums,
+                                                           int HW, uint8_t* __restrict__ out_u8, float* __restrict__ out_f,
+                                                           float m0, float m1, float m2, float s0, float s1, float s2) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = t < HW;
+  const float fb = factors[4 * b], fc = factors[4 * b + 1], fsat = factors[4 * b + 2], fh = factors[4 * b + 3];   // NaN: adjustment off
+  const uint32_t ord = *reinterpret_cast<const uint32_t*>(order + 4 * b);
+  int px[3] = {0, 0, 0};
+  if (live) {
+    const uint8_t* p = in + ((size_t)b * HW + t) * 3;
+    px[0] = p[0]; px[1] = p[1]; px[2] = p[2];
+  }
+  bool stop = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int fn = (ord >> (8 * k)) & 0xff;
+    if (stop) continue;
+    if (fn == 0 && fb == fb) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) px[c] = jit_blend(0, px[c], fb);
+    } else if (fn == 1 && fc == fc) {
+      if (!FINAL) { stop = true; continue; }
+      const unsigned long long sum = sums[b];
+      const int mean = (int)((double)sum / (double)HW + 0.5);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) px[c] = jit_blend(mean, px[c], fc);
+    } else if (fn == 2 && fsat == fsat) {
+      const int L = jit_l(px);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) px[c] = jit_blend(L, px[c], fsat);
+    } else if (fn == 3 && fh == fh) {
+      jit_hue(px, (int)fh & 255);
+    }
+  }
+  if (!FINAL) {
+    // every image needs its sum only if contrast is on; summing regardless keeps the control flow uniform
+    unsigned long long v = live ? (unsigned long long)jit_l(px) : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && fc == fc) atomicAdd(sums + b, v);
+    return;
+  }
+  if (!live) return;
+  if (out_u8) {
+    uint8_t* o = out_u8 + ((size_t)b * HW + t) * 3;
+    o[0] = (uint8_t)px[0]; o[1] = (uint8_t)px[1]; o[2] = (uint8_t)px[2];
+  }
+  if (out_f) {
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float tt = (float)px[c] / 255.0f;                      // ToTensor, then Normalize: torch's operation order
+      out_f[((size_t)b * 3 + c) * HW + t] = (tt - mean[c]) / sd[c];
+    }
+  }
+}
+
 static inline long long align16(long long v) { return (v + 15) & ~15LL; }
 static inline int host_ksize(int in, int out) {
   const double scale = (double)in / (double)out;
@@ -272,6 +395,23 @@ int vqa_image_resize(const uint8_t* in, const long long* in_off, const int* H, c
     hipLaunchKernelGGL(resize_v_kernel, dim3((unsigned)((OH * OW + 255) / 256), (unsigned)cnt), dim3(256), 0, st, g, in, (const uint8_t*)ws, b0,
                        RH, RW, OH, OW, out_u8, out_nchw, flip, mean0, mean1, mean2, std0, std1, std2);
   }
+  VQA_LAUNCH_CHECK();
+  return VQA_OK;
+}
+
+int vqa_image_color_jitter(const uint8_t* in_hwc, const uint8_t* order, const float* factors, int B, int H, int W, uint8_t* out_u8,
+                           float* out_nchw, float mean0, float mean1, float mean2, float std0, float std1, float std2,
+                           unsigned long long* sums, hipStream_t st) {
+  if (!in_hwc || !order || !factors || !sums || B <= 0 || H <= 0 || W <= 0 || (!out_u8 && !out_nchw)) return VQA_EARG;
+  if ((long long)H * W > 0x7fffffffLL / 4 || B > 65535) return VQA_EARG;
+  if (out_nchw && !(std0 != 0.f && std1 != 0.f && std2 != 0.f)) return VQA_EARG;
+  const int HW = H * W;
+  const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)B);
+  if (hipMemsetAsync(sums, 0, (size_t)B * sizeof(unsigned long long), st) != hipSuccess) return VQA_EARG;
+  hipLaunchKernelGGL(color_jitter_kernel<false>, grid, dim3(256), 0, st, in_hwc, order, factors, sums, HW, (uint8_t*)nullptr, (float*)nullptr,
+                     0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
+  hipLaunchKernelGGL(color_jitter_kernel<true>, grid, dim3(256), 0, st, in_hwc, order, factors, sums, HW, out_u8, out_nchw,
+                     mean0, mean1, mean2, std0, std1, std2);
   VQA_LAUNCH_CHECK();
   return VQA_OK;
 }
