@@ -471,38 +471,13 @@ class HipEngine:
         phead = cfg["answer_dropout"] if training else 0.0
         dev = images.device
 
-        # ---- text encoder, A6-A8 (issued first, on the side stream; joined before fusion)
+        # The stem's three launches go out FIRST (0.6 ms of GPU work): a caller that synchronises every step (training/train.py:211
+        # loss.item()) starts each forward with an idle GPU, and the ~100 tiny text-encoder launches issued ahead of the stem left
+        # it idle for the millisecond the host needs to enqueue them.  The side stream still waits only for what preceded the stem.
         main = torch.cuda.current_stream()
         use_side = self.two_streams and self.side is not None
         if use_side:
             ev0 = torch.cuda.Event(); ev0.record(main)
-            self.side.wait_event(ev0)                    # weights cast + everything earlier on main is visible to the side stream
-        with torch.cuda.stream(self.side if use_side else main):
-            d, heads = cfg["embed_dim"], cfg["num_attention_heads"]
-            hd = d // heads
-            Bt, L = token_ids.shape
-            rows = Bt * L
-            pe = self.buf["text_encoder.positional_encoding.pe"]
-            if L > pe.shape[1]:
-                raise RuntimeError(f"sequence length {L} exceeds max_question_length {pe.shape[1]}")
-            emb_e = self.E["text_encoder.token_embedding.weight"]
-            sd0 = self._seed()
-            xt = torch.empty((rows, d), device=dev, dtype=T)
-            call("vqa_embed_fwd", dt(T), ptr(token_ids), ptr(self.P(emb_e.name)), ptr(pe), ptr(xt), rows, L, d, emb_e.shape[0],
-                 math.sqrt(d), float(pdrop), sd0)
-            tape["embed"] = dict(ids=token_ids, seed=sd0, p=pdrop)
-            tape["tlayers"] = []
-            for l in range(cfg["num_transformer_layers"]):
-                p = f"text_encoder.layers.{l}"
-                rec = self._attn_block_fwd(xt, xt, None, p + ".norm1", None, p + ".self_attention", maskf, Bt, L, L, heads, hd, pdrop,
-                                           p + ".norm2", p + ".ffn.fc1", p + ".ffn.fc2", self_attn=True)
-                tape["tlayers"].append(rec)
-                xt = rec["out"]
-            enc, enc_st = self._ln(xt, "text_encoder.final_norm")
-            tape["final_norm"] = dict(x=xt, st=enc_st)
-
-            ev_txt = torch.cuda.Event(); ev_txt.record()
-
         # ---- stem: conv7x7/2 (from the NCHW fp32 image) + BN + ReLU + maxpool, A1
         H1, W1 = (IH + 6 - 7) // 2 + 1, (IW + 6 - 7) // 2 + 1
         M = B * H1 * W1
@@ -518,6 +493,41 @@ class HipEngine:
         call("vqa_stem_pool_fwd", dt(T), ptr(y), ptr(coef), ptr(x), ptr(idx), B, H1, W1, 64)
         tape["stem"] = dict(images=images, y=y, coef=coef, idx=idx, geom=sgeom, H1=H1, W1=W1)
         H, W, C = Hp, Wp, 64
+        # ---- text encoder, A6-A8 (on the side stream; joined before fusion).  Issued behind stage 1: by then the GPU holds > 1 ms of
+        #      queued work, which covers the millisecond the host spends on these ~100 launches (see the stem note above).
+        d, heads = cfg["embed_dim"], cfg["num_attention_heads"]
+        hd = d // heads
+        Bt, L = token_ids.shape
+        rows = Bt * L
+        pe = self.buf["text_encoder.positional_encoding.pe"]
+        if L > pe.shape[1]:
+            raise RuntimeError(f"sequence length {L} exceeds max_question_length {pe.shape[1]}")
+        text = {}
+
+        def issue_text():
+          if use_side:
+            self.side.wait_event(ev0)                    # weights cast + everything earlier on main is visible to the side stream
+          with torch.cuda.stream(self.side if use_side else main):
+            emb_e = self.E["text_encoder.token_embedding.weight"]
+            sd0 = self._seed()
+            xt = torch.empty((rows, d), device=dev, dtype=T)
+            call("vqa_embed_fwd", dt(T), ptr(token_ids), ptr(self.P(emb_e.name)), ptr(pe), ptr(xt), rows, L, d, emb_e.shape[0],
+                 math.sqrt(d), float(pdrop), sd0)
+            tape["embed"] = dict(ids=token_ids, seed=sd0, p=pdrop)
+            tape["tlayers"] = []
+            for l in range(cfg["num_transformer_layers"]):
+                p = f"text_encoder.layers.{l}"
+                rec = self._attn_block_fwd(xt, xt, None, p + ".norm1", None, p + ".self_attention", maskf, Bt, L, L, heads, hd, pdrop,
+                                           p + ".norm2", p + ".ffn.fc1", p + ".ffn.fc2", self_attn=True)
+                tape["tlayers"].append(rec)
+                xt = rec["out"]
+            enc, enc_st = self._ln(xt, "text_encoder.final_norm")
+            text["enc"] = enc
+            tape["final_norm"] = dict(x=xt, st=enc_st)
+
+            ev_txt = torch.cuda.Event(); ev_txt.record()
+            text["ev"] = ev_txt
+
         if self.mark: self.mark("forward: stem")
 
         # ---- residual stages, A2-A5
@@ -606,6 +616,8 @@ class HipEngine:
                 srec["spatial"] = dict(x=x, pooled2=pooled2, amax=amax, amap=amap, H=H, W=W, C=C)
                 x = out
             tape["stages"].append(srec)
+            if s == 1:
+                issue_text()
             if self.mark: self.mark(f"forward: stage{s}")
         feat = x                                  # [B*Hf*Wf, 512] == tokens of the projector (NHWC makes the permute free)
         Hf, Wf, Cf = H, W, C
@@ -613,6 +625,7 @@ class HipEngine:
         tape["feat"] = dict(Hf=Hf, Wf=Wf, Cf=Cf)
 
         # ---- fusion, A9-A11
+        enc, ev_txt = text["enc"], text["ev"]
         if use_side:
             main.wait_event(ev_txt)
         pj = "fusion.image_projector.projection"
