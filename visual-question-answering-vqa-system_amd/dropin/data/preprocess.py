@@ -148,6 +148,7 @@ class DeviceImageResizer:
         self.mean, self.std = [float(m) for m in mean], [float(s) for s in std]
         self.device = torch.device(device)
         self._L = _pkg()._lib
+        self._stage, self._stage_ev, self._stage_i = [None, None], [None, None], 0
 
     def __call__(self, images, crop_yx=None, flip: Optional[torch.Tensor] = None, return_u8: bool = False, jitter_params=None, generator=None):
         import ctypes as C
@@ -169,11 +170,17 @@ class DeviceImageResizer:
             packed = torch.empty(off, dtype=torch.uint8, device=self.device)
             for t, o in zip(ts, offs):
                 packed[o: o + t.numel()] = t.reshape(-1)
-        else:                                        # one staging buffer, one upload
-            host = torch.empty(off, dtype=torch.uint8, pin_memory=True)
+        else:                                        # one pinned staging buffer (two, alternating: kept across calls), one upload
+            k = self._stage_i = 1 - self._stage_i
+            if self._stage[k] is None or self._stage[k].numel() < off:
+                self._stage[k] = torch.empty(max(off, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=True)   # pinning costs milliseconds: not per call
+            elif self._stage_ev[k] is not None:
+                self._stage_ev[k].synchronize()      # the upload that last read this buffer has finished
+            host = self._stage[k][:off]
             for t, o in zip(ts, offs):
-                host[o: o + t.numel()] = t.reshape(-1).cpu()
+                host[o: o + t.numel()].copy_(t.reshape(-1))
             packed = host.to(self.device, non_blocking=True)
+            self._stage_ev[k] = torch.cuda.Event(); self._stage_ev[k].record()
         IA, LA = C.c_int * n, C.c_longlong * n
         Ha, Wa, Oa = IA(*Hs), IA(*Ws), LA(*offs)
         crop = None

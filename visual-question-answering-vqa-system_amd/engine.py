@@ -505,28 +505,25 @@ class HipEngine:
         text = {}
 
         def issue_text():
-          if use_side:
-            self.side.wait_event(ev0)                    # weights cast + everything earlier on main is visible to the side stream
-          with torch.cuda.stream(self.side if use_side else main):
-            emb_e = self.E["text_encoder.token_embedding.weight"]
-            sd0 = self._seed()
-            xt = torch.empty((rows, d), device=dev, dtype=T)
-            call("vqa_embed_fwd", dt(T), ptr(token_ids), ptr(self.P(emb_e.name)), ptr(pe), ptr(xt), rows, L, d, emb_e.shape[0],
-                 math.sqrt(d), float(pdrop), sd0)
-            tape["embed"] = dict(ids=token_ids, seed=sd0, p=pdrop)
-            tape["tlayers"] = []
-            for l in range(cfg["num_transformer_layers"]):
-                p = f"text_encoder.layers.{l}"
-                rec = self._attn_block_fwd(xt, xt, None, p + ".norm1", None, p + ".self_attention", maskf, Bt, L, L, heads, hd, pdrop,
-                                           p + ".norm2", p + ".ffn.fc1", p + ".ffn.fc2", self_attn=True)
-                tape["tlayers"].append(rec)
-                xt = rec["out"]
-            enc, enc_st = self._ln(xt, "text_encoder.final_norm")
-            text["enc"] = enc
-            tape["final_norm"] = dict(x=xt, st=enc_st)
-
-            ev_txt = torch.cuda.Event(); ev_txt.record()
-            text["ev"] = ev_txt
+            if use_side:
+                self.side.wait_event(ev0)                # weights cast + everything earlier on main is visible to the side stream
+            with torch.cuda.stream(self.side if use_side else main):
+                emb_e = self.E["text_encoder.token_embedding.weight"]
+                sd0 = self._seed()
+                xt = torch.empty((rows, d), device=dev, dtype=T)
+                call("vqa_embed_fwd", dt(T), ptr(token_ids), ptr(self.P(emb_e.name)), ptr(pe), ptr(xt), rows, L, d, emb_e.shape[0],
+                     math.sqrt(d), float(pdrop), sd0)
+                tape["embed"] = dict(ids=token_ids, seed=sd0, p=pdrop)
+                tape["tlayers"] = []
+                for l in range(cfg["num_transformer_layers"]):
+                    p = f"text_encoder.layers.{l}"
+                    rec = self._attn_block_fwd(xt, xt, None, p + ".norm1", None, p + ".self_attention", maskf, Bt, L, L, heads, hd, pdrop,
+                                               p + ".norm2", p + ".ffn.fc1", p + ".ffn.fc2", self_attn=True)
+                    tape["tlayers"].append(rec)
+                    xt = rec["out"]
+                text["enc"], enc_st = self._ln(xt, "text_encoder.final_norm")
+                tape["final_norm"] = dict(x=xt, st=enc_st)
+                text["ev"] = torch.cuda.Event(); text["ev"].record()
 
         if self.mark: self.mark("forward: stem")
 
