@@ -9,6 +9,7 @@
 //   stats: per-workgroup column sums / sums of squares [gridDim][2][64] for train-mode BatchNorm
 #include <cstdlib>
 #include "common.h"
+#include <type_traits>
 #include "stem_route.h"
 
 namespace {
@@ -213,22 +214,26 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       const int dyr_b = (((b * Ho + oh0 + orow) * Wo + px0) * 64) * 2;     // byte offset of the row piece (32-bit buffer addressing)
       if constexpr (FUSED) {
         // item = (pixel pair (2q, 2q+1) of the piece, channel vector): the pair shares its pooling windows (stem_route_pair_buf)
-        for (int v = tid; v < (Wh >> 1) * 8; v += 256) {
-          const int pq = v >> 3, cv = v & 7;
-          Vec16<bf16_t> yy[2];
-          yy[0].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsDy, dyr_b + (2 * pq) * 128 + cv * 16, 0, 0));
-          yy[1].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsDy, dyr_b + (2 * pq + 1) * 128 + cv * 16, 0, 0));
-          float g8[2][8];
-          stem_route_pair_buf(rsP, rsI, yy, f_sc, f_sh, b, oh0 + orow, (px0 >> 1) + pq, cv * 8, Hp, Wp, g8);
+        auto stage_row = [&](auto odd) {             // the row's parity picks the body: two pooling-window rows, or one
+          for (int v = tid; v < (Wh >> 1) * 8; v += 256) {
+            const int pq = v >> 3, cv = v & 7;
+            Vec16<bf16_t> yy[2];
+            yy[0].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsDy, dyr_b + (2 * pq) * 128 + cv * 16, 0, 0));
+            yy[1].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsDy, dyr_b + (2 * pq + 1) * 128 + cv * 16, 0, 0));
+            float g8[2][8];
+            stem_route_pair_buf<decltype(odd)::value>(rsP, rsI, yy, f_sc, f_sh, b, oh0 + orow, (px0 >> 1) + pq, cv * 8, Hp, Wp, g8);
 #pragma unroll
-          for (int q2 = 0; q2 < 2; ++q2) {
-            Vec16<bf16_t> o;
+            for (int q2 = 0; q2 < 2; ++q2) {
+              Vec16<bf16_t> o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o.set(j, f_a[j] * g8[q2][j] + f_b[j] * yy[q2].get(j) + f_c[j]);
-            uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[(2 * pq + q2) * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned
-            d[0] = o.raw[0]; d[1] = o.raw[1]; d[2] = o.raw[2]; d[3] = o.raw[3];
+              for (int j = 0; j < 8; ++j) o.set(j, f_a[j] * g8[q2][j] + f_b[j] * yy[q2].get(j) + f_c[j]);
+              uint32_t* d = reinterpret_cast<uint32_t*>(&Dy[(2 * pq + q2) * LDD + cv * 8]);     // LDD*2 = 136 B rows: 8-byte aligned
+              d[0] = o.raw[0]; d[1] = o.raw[1]; d[2] = o.raw[2]; d[3] = o.raw[3];
+            }
           }
-        }
+        };
+        if ((oh0 + orow) & 1) stage_row(std::true_type{});
+        else stage_row(std::false_type{});
       } else {
         for (int v = tid; v < Wh * 8; v += 256) {
           const int px = v >> 3, cv = v & 7;

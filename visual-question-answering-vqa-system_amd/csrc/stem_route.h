@@ -73,11 +73,13 @@ __device__ __forceinline__ void stem_route_buf(__amdgpu_buffer_rsrc_t rsP, __amd
 
 // The same routing for TWO horizontally adjacent pixels (h, 2j) and (h, 2j+1) at once: column 2j lies in pooling-window column j only
 // (s = 1), column 2j+1 in window columns j (s = 2) and j+1 (s = 0); window rows: odd h lies in rows (h-1)/2 (r = 2) and (h+1)/2 (r = 0),
-// even h only in row h/2 (r = 1) -- (h-1)>>1 is then a window that does not contain h (r = 3: its codes 9..11 never equal an argmax
-// byte, so the pass adds nothing).  That pass is NOT branched around: measured on MI355X, a wave-uniform `continue` for even rows
-// splits the two batched load groups into dependent ones and the fused stem weight gradient goes 0.69 -> 0.95 ms.  2 or 4
-// window loads and unpacks for 2 pixels instead of 4 per pixel -- the staging of the fused stem weight gradient is VALU-bound.  Sums
-// are formed in the same order as stem_route (window row a before b, column j before j+1), so the values are bit-identical.
+// even h only in row h/2 (r = 1).  The row parity is a TEMPLATE parameter: the caller branches once per image row (wave-uniform) into
+// a body with two window-row passes or with one, each with all its loads in one batch.  (A run-time `continue` around the needless
+// pass of even rows inside ONE body split the batched loads into dependent groups: 0.69 -> 0.95 ms for the fused stem weight
+// gradient on MI355X.)  2 or 4 window loads and unpacks for 2 pixels instead of 4 per pixel -- the staging of the fused stem weight
+// gradient is VALU-bound.  Sums are formed in the same order as stem_route (window row a before b, column j before j+1), so the
+// values are bit-identical.
+template <bool ODD>
 __device__ __forceinline__ void stem_route_pair_buf(__amdgpu_buffer_rsrc_t rsP, __amdgpu_buffer_rsrc_t rsI, const Vec16<bf16_t> (&yy)[2],
                                                     const float* sc, const float* sh, int b, int h, int j, int c0, int Ho, int Wo,
                                                     float (&g)[2][8]) {
@@ -86,11 +88,11 @@ __device__ __forceinline__ void stem_route_pair_buf(__amdgpu_buffer_rsrc_t rsP, 
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int jx = 0; jx < 8; ++jx) g[q][jx] = 0.f;
-  const int oh_a = (h - 1) >> 1, oh_b = (h + 1) >> 1;
+  constexpr int NP = ODD ? 2 : 1;
 #pragma unroll
-  for (int kr = 0; kr < 2; ++kr) {
-    if (kr == 1 && oh_b == oh_a) break;                       // (never taken for valid rows; keeps both passes' loads in one batch)
-    const int oh = kr ? oh_b : oh_a, r = h - (oh * 2 - 1);
+  for (int kr = 0; kr < NP; ++kr) {
+    const int oh = ODD ? ((h - 1) >> 1) + kr : (h >> 1);
+    const int r = ODD ? (kr ? 0 : 2) : 1;                     // = h - (2 * oh - 1)
     const bool rok = oh >= 0 && oh < Ho;
     const int ohc = min(max(oh, 0), Ho - 1);
     Vec16<bf16_t> d[2]; u32x2_t iw[2]; bool ok[2];
