@@ -68,17 +68,21 @@ print(f"  the same batch: already on the GPU {phase(lambda: aug(raw_dev, crop_yx
 # where the host half of that call goes: tensor wrapping, packing into the pinned buffer, the upload
 stage = torch.empty(100 << 20, dtype=torch.uint8, pin_memory=True)
 pageable = torch.empty(100 << 20, dtype=torch.uint8)
-def pack(dst):
+def pack(dst, use_numpy=True):
     ts = [torch.as_tensor(r).contiguous() for r in raw]
-    o = 0
+    o, dn = 0, dst.numpy()
     for t in ts:
-        dst[o: o + t.numel()].copy_(t.reshape(-1)); o += (t.numel() + 15) // 16 * 16
+        if use_numpy:
+            dn[o: o + t.numel()] = t.reshape(-1).numpy()
+        else:
+            dst[o: o + t.numel()].copy_(t.reshape(-1))
+        o += (t.numel() + 15) // 16 * 16
     return o
 nbytes = pack(stage)
 t_wrap = phase(lambda: [torch.as_tensor(r).contiguous() for r in raw])
-t_pin, t_page = phase(lambda: pack(stage)), phase(lambda: pack(pageable))
+t_pin, t_page, t_torch = phase(lambda: pack(stage)), phase(lambda: pack(pageable)), phase(lambda: pack(stage, False))
 t_up = phase(lambda: stage[:nbytes].to(dev, non_blocking=True))
-print(f"  host half: wrap {t_wrap:.2f} ms, pack {nbytes/1e6:.0f} MB into pinned memory {t_pin:.1f} ms (into pageable memory {t_page:.1f} ms), upload {t_up:.1f} ms; torch threads {torch.get_num_threads()}")
+print(f"  host half: wrap {t_wrap:.2f} ms, pack {nbytes/1e6:.0f} MB into pinned memory {t_pin:.1f} ms (into pageable memory {t_page:.1f} ms; with torch copy_ on {torch.get_num_threads()} threads {t_torch:.1f} ms), upload {t_up:.1f} ms = {nbytes/t_up/1e6:.1f} GB/s")
 print(f"training transform, 128 decoded images of 300-480 x 400-640 from host memory: {th*1e3:.1f} ms per batch = {len(raw)/th/1e3:.1f} k images/s (upload included)")
 tok = T.Tokenizer(max_length=20, vocab_size=10000)
 words = [f"w{i}" for i in range(5000)]
