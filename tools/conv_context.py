@@ -60,3 +60,33 @@ cases = [("single launch, GPU just synchronised", lambda: None),
 for name, pre in cases:
     med, lo, hi = timed(pre)
     print(f"{name:38s}{med:7.1f} us (min {lo:.1f}, max {hi:.1f})  {fl/med/1e6:6.1f} TF/s", flush=True)
+
+
+# ---- sustained activity, no host sync between launches: what the conv sees inside the step
+def sustained(label, pre, conv_i, n=40):
+    evs = []
+    for i in range(n):
+        pre(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); conv_i(i); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs[8:])
+    med = ts[len(ts) // 2]
+    print(f"{label:62s}{med:7.1f} us (min {ts[0]:.1f}, max {ts[-1]:.1f})  {fl/med/1e6:6.1f} TF/s", flush=True)
+
+
+NB = 10                                                    # 10 x (51 + 51 MB) = 1 GB: more than the 256 MB Infinity Cache
+xs = [torch.randn(M, C, device=dev).to(T) for _ in range(NB)]
+outs = [torch.empty(M, C, device=dev, dtype=T) for _ in range(NB)]
+ws = [K.pack_rows(torch.randn(C, Kw, device=dev) * 0.05, T) for _ in range(NB)]
+print("no host sync between launches (events around each conv):")
+sustained("same buffers every launch", lambda i: None, lambda i: K.igemm(x, wp, M, C, Kw, geom, dtype=T, out=out))
+sustained("10 input / output / weight sets in turn (cold Infinity Cache)", lambda i: None,
+          lambda i: K.igemm(xs[i % NB], ws[i % NB], M, C, Kw, geom, dtype=T, out=outs[i % NB]))
+sustained("same buffers, input rewritten by a copy kernel before each launch", lambda i: x.copy_(x2),
+          lambda i: K.igemm(x, wp, M, C, Kw, geom, dtype=T, out=out))
+sustained("10 sets in turn, each input rewritten just before its launch", lambda i: xs[i % NB].copy_(x2),
+          lambda i: K.igemm(xs[i % NB], ws[i % NB], M, C, Kw, geom, dtype=T, out=outs[i % NB]))
+sustained("10 sets in turn, 512 MB of unrelated traffic before each launch", lambda i: big2.copy_(big),
+          lambda i: K.igemm(xs[i % NB], ws[i % NB], M, C, Kw, geom, dtype=T, out=outs[i % NB]))
