@@ -277,3 +277,10 @@ JITTER_CASES = [
     ("identity_factors", 32, 48, 30, 8, (2, 1, 3, 0), 1.0, 1.0, 1.0, 0.0),
     ("zero_factors", 32, 48, 31, 8, (0, 2, 1, 3), 0.0, 0.0, 0.0, 0.002),
 ]
+
+# one case of tests/golden/jitter_pil.npz runs the WHOLE training transform of data/preprocess.py:66-84 in the real PIL:
+# (tag, H, W, seed, noise bits, resize, crop, (cy, cx), flip, order, brightness, contrast, saturation, hue)
+PIPELINE_CASES = [
+    ("train_pipeline_a", 333, 500, 41, 5, 256, 224, (16, 5), 1, (1, 3, 0, 2), 1.17, 0.83, 1.1, -0.08),
+    ("train_pipeline_b", 480, 360, 42, 5, 256, 224, (0, 32), 0, (3, 0, 2, 1), 0.84, 1.19, 0.81, 0.1),
+]

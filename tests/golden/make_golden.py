@@ -260,6 +260,13 @@ def gen_jitter():
         warnings.simplefilter("ignore")
         for tag, H, W, seed, nb, order, b, c, s_, h in IO.JITTER_CASES:
             out[f"{tag}_u8"] = pil_color_jitter(IO.pattern_image(H, W, seed, nb), order, b, c, s_, h)
+        from PIL import Image
+        for tag, H, W, seed, nb, S, crop, (cy, cx), flip, order, b, c, s_, h in IO.PIPELINE_CASES:     # the whole training transform
+            pil = Image.fromarray(IO.pattern_image(H, W, seed, nb), mode="RGB").resize((S, S), Image.BILINEAR)
+            pil = pil.crop((cx, cy, cx + crop, cy + crop))
+            if flip:
+                pil = pil.transpose(Image.FLIP_LEFT_RIGHT)
+            out[f"{tag}_u8"] = pil_color_jitter(np.array(pil, copy=True), order, b, c, s_, h)
     np.savez_compressed(os.path.join(OUT, "jitter_pil.npz"), **out)
     print("jitter_pil", len(IO.JITTER_CASES), "cases", os.path.getsize(os.path.join(OUT, "jitter_pil.npz")), "bytes")
 

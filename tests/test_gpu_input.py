@@ -190,6 +190,20 @@ def test_device_color_jitter_bit_exact_against_pil(jgold, case):
     assert torch.equal(out.cpu(), IO.to_tensor_normalize(torch.from_numpy(jgold[f"{tag}_u8"])[None]))
 
 
+@pytest.mark.parametrize("case", IO.PIPELINE_CASES, ids=[c[0] for c in IO.PIPELINE_CASES])
+def test_device_training_transform_bit_exact_against_pil(jgold, case):
+    """get_train_transforms(use_augmentation=True) (data/preprocess.py:66-84) in ONE resizer call against the same chain run by the real
+    PIL: Resize(256) -> crop window -> flip -> ColorJitter (uint8, bit for bit) -> ToTensor -> Normalize."""
+    tag, H, W, seed, nb, S, crop, (cy, cx), flip, order, b, c, s, h = case
+    P = pkg().load_dropin_preprocess()
+    rz = P.DeviceImageResizer(size=S, crop=crop, jitter=P.DeviceColorJitter(0.2, 0.2, 0.2, 0.1))
+    out, u8 = rz([IO.pattern_image(H, W, seed, nb)], crop_yx=[(cy, cx)], flip=torch.tensor([bool(flip)]), return_u8=True,
+                 jitter_params=(torch.tensor([order]), _factors(b, c, s, h)))
+    torch.cuda.synchronize()
+    assert np.array_equal(u8[0].cpu().numpy(), jgold[f"{tag}_u8"])
+    assert torch.equal(out.cpu(), IO.to_tensor_normalize(torch.from_numpy(jgold[f"{tag}_u8"])[None]))
+
+
 def test_device_hue_round_trip_on_every_colour():
     """RGB -> HSV -> (+delta) -> RGB for all 2^24 colours (a 4096 x 4096 image) at three shifts, and the saturation / brightness blends
     on the same image, against the numpy restatement that tests/test_input_cpu.py pins to the real PIL over the same full domain."""

@@ -122,6 +122,16 @@ def test_oracle_color_jitter_is_bit_exact_against_pil(jgold, case):
     assert got.dtype == np.uint8 and np.array_equal(got, jgold[f"{tag}_u8"])
 
 
+@pytest.mark.parametrize("case", IO.PIPELINE_CASES, ids=[c[0] for c in IO.PIPELINE_CASES])
+def test_oracle_training_transform_matches_pil_end_to_end(jgold, case):
+    """Resize(256) -> RandomCrop(224) window -> flip -> ColorJitter, every step run by the real PIL (golden) vs the chained restatements."""
+    tag, H, W, seed, nb, S, crop, (cy, cx), flip, order, b, c, s, h = case
+    x = IO.pil_resize_bilinear(IO.pattern_image(H, W, seed, nb), S, S)[cy: cy + crop, cx: cx + crop]
+    if flip:
+        x = x[:, ::-1]
+    assert np.array_equal(IO.color_jitter(np.ascontiguousarray(x), order, b, c, s, h), jgold[f"{tag}_u8"])
+
+
 def _all_colours():
     return np.stack(np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij"), -1).reshape(4096, 4096, 3).astype(np.uint8)
 
