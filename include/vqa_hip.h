@@ -90,6 +90,11 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
 int vqa_stem_conv_blocks(int B, int H, int W);
 int vqa_stem_pack(const float* w_krsc, void* wstem, hipStream_t stream);
 int vqa_stem_conv(const float* img, const void* wstem, void* out, float* stats, int B, int H, int W, hipStream_t stream);
+/* Inference stem in ONE launch: conv7x7/2 + BatchNorm with running statistics (coef = scale[64] | shift[64], vqa_bn_eval_coef) + ReLU +
+   MaxPool3x3/2 p1 (models/cnn_backbone.py:349-354 in eval mode).  out: the pooled activation NHWC bf16 [B][Hp][Wp][64]; the conv
+   output itself is never stored (no argmax either: no backward).  vqa_stem_conv_pool_ok: 1 when the shape is supported. */
+int vqa_stem_conv_pool_ok(int B, int H, int W);
+int vqa_stem_conv_pool(const float* img, const void* wstem, const float* coef, void* out, int B, int H, int W, hipStream_t stream);
 int vqa_stem_wgrad_blocks(int B, int H, int W);   /* workgroups of the two stem weight-gradient kernels; their scratch: blocks * 64*147 floats */
 int vqa_stem_wgrad(const float* img, const void* dy, float* dw /* [64][7][7][3] += */, int B, int H, int W,
                    float* ws /* scratch or NULL: atomics */, long long ws_floats, hipStream_t stream);

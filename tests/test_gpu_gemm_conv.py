@@ -188,6 +188,43 @@ def test_stem_conv_bf16_dedicated_kernel(hw):
     assert _relerr(s[0], y_ref.sum(0)) < 5e-3 and _relerr(s[1], (y_ref ** 2).sum(0)) < 5e-3
 
 
+@pytest.mark.parametrize("hw", [(224, 224), (64, 64), (96, 160), (384, 384), (32, 72)])
+def test_inference_stem_in_one_launch(hw):
+    """vqa_stem_conv_pool == conv7x7/2 -> BatchNorm(running statistics) -> ReLU -> MaxPool3x3/2 (models/cnn_backbone.py:349-354, eval):
+    against ATen on the bf16-rounded image / weights (fp32 math: the fused kernel normalises the fp32 accumulators, so only the final
+    bf16 rounding differs), and against the two-kernel path (which rounds the conv output to bf16 first).  Shapes: the benchmark's,
+    the stress config's, ragged last column tiles (pooled width 40 / 18: not a multiple of 7), two and four row blocks per image."""
+    K, L = sub("kernels"), sub("_lib")
+    H, W = hw
+    B = 3
+    g = torch.Generator().manual_seed(H * 7 + W)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = _round(torch.randn(64, 3, 7, 7, generator=g) * 0.1, torch.bfloat16)
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.5
+    y = F.conv2d(_round(img, torch.bfloat16), w, None, stride=2, padding=3)
+    ref = F.max_pool2d(torch.relu(y * scale[None, :, None, None] + shift[None, :, None, None]), 3, 2, 1)
+    Hp, Wp = ref.shape[2], ref.shape[3]
+    assert L.count("vqa_stem_conv_pool_ok", B, H, W) == 1
+    wst = torch.empty(64, 192, device=DEV, dtype=torch.bfloat16)
+    L.call("vqa_stem_pack", w.permute(0, 2, 3, 1).contiguous().to(DEV).data_ptr(), wst.data_ptr())
+    coef = torch.cat([scale, shift, torch.zeros(128)]).to(DEV)
+    x = K.stem_conv_pool(img.to(DEV), wst, coef, B, H, W)
+    torch.cuda.synchronize()
+    assert x.shape == (B * Hp * Wp, 64)
+    got = x.float().cpu().view(B, Hp, Wp, 64).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())          # one bf16 rounding of the result
+    # the two-kernel path: conv -> bf16 y -> BN + ReLU + pool
+    if K.stem_conv_blocks(B, H, W) > 0:
+        y2, _, _ = K.stem_conv(img.to(DEV), wst, B, H, W, False)
+        x2 = torch.empty_like(x); idx = torch.empty(x.shape, device=DEV, dtype=torch.uint8)
+        L.call("vqa_stem_pool_fwd", 1, y2.data_ptr(), coef.data_ptr(), x2.data_ptr(), idx.data_ptr(), B, y.shape[2], y.shape[3], 64)
+        torch.cuda.synchronize()
+        assert (x.float() - x2.float()).abs().max().item() <= 2e-2 * max(1.0, float(x2.float().abs().max()))
+    # unsupported shapes are refused, not mis-computed: odd conv output, pooled rows not a multiple of 4
+    assert L.count("vqa_stem_conv_pool_ok", B, 226, 224) == 0 and L.count("vqa_stem_conv_pool_ok", B, 40, 40) == 0
+    assert K.stem_conv_pool(img.to(DEV)[:, :, :40, :40].contiguous(), wst, coef, B, 40, 40) is None
+
+
 @pytest.mark.parametrize("hw", [(224, 224), (64, 64), (96, 160)])
 def test_stem_wgrad_bf16_dedicated_kernel(hw):
     K = sub("kernels")

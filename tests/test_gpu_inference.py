@@ -127,3 +127,29 @@ def test_graph_cache_is_lru_and_outputs_are_owned_by_the_caller():
         o3, _ = m(im[:1], idd[:1], None)
     torch.cuda.synchronize()
     assert torch.equal(o3, o1)
+
+
+def test_inference_stem_fusion_keeps_the_logits():
+    """eval + no_grad forward with the one-launch stem (default) against the same model with it switched off: logits within the
+    bf16 path's tolerance, identical top-1; the HIP-graph replay uses the fused stem too (same logits as the eager call)."""
+    m = _model("bf16")
+    torch.manual_seed(3)
+    B = 8
+    images = torch.randn(B, 3, 224, 224, device=DEV)
+    ids = torch.randint(1, 900, (B, 20), device=DEV)
+    mask = torch.ones(B, 20, dtype=torch.long, device=DEV)
+    m.eval()
+    with torch.no_grad():
+        a, _ = m(images, ids, mask)
+        eng = m._ensure_engine()
+        assert eng.fuse_stem_eval
+        eng.fuse_stem_eval = False
+        m._graphs.clear() if hasattr(m, "_graphs") else None
+        m.graph_inference = False
+        b, _ = m(images, ids, mask)
+        eng.fuse_stem_eval = True
+        c, _ = m(images, ids, mask)                    # eager, fused stem
+    torch.cuda.synchronize()
+    assert (a - b).abs().max().item() < 6e-2 * max(1.0, float(b.abs().max()))
+    assert torch.equal(a.argmax(-1), b.argmax(-1))
+    assert torch.equal(a, c)

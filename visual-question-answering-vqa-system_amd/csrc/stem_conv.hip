@@ -20,6 +20,50 @@ constexpr int LDW = KP + 8;    // weight row stride in LDS (elements)
 constexpr int LDCS = 64 + 8;   // C staging row stride
 }
 
+// patch[3][PROWS][PW] (bf16, x = iw + XO) <- img[b][c][ih_base + pr][iw], zero outside the image.  The NCHW fp32 image is read with
+// 16-byte loads, CH of them in flight per thread: with one 4-byte load per (row, column), three dependent batches of 23, the fill --
+// not the MFMA loop, not HBM -- bounded the one-launch inference stem (380 of its 705 us at 1.2 TB/s; 386 us with this fill,
+// tools/bench_stem_eval.py).  The training kernels keep their scalar fills: stem_conv_kernel issues all 39 loads of a thread in ONE
+// batch and measured the same either way (674 vs 680 us with the pooling pass, step 12.94 vs 12.89 ms), and inlined into the fused
+// weight-gradient kernel this function costs it a workgroup per CU (171 vs 118 registers: 709 -> 940 us).
+// W % 4 == 0 (other widths take the scalar loop).  XO is odd, so the four bf16 of an item sit at an odd
+// element: one 4-byte store between two 2-byte ones.
+template <int PROWS, int XO, int CH>
+__device__ __forceinline__ void stem_fill_patch(bf16_t* __restrict__ patch, int PW, __amdgpu_buffer_rsrc_t rsImg, int b, int ih_base,
+                                                int H, int W, int tid) {
+  static_assert(XO & 1, "odd column offset");
+  const int W4 = W >> 2, nitems = 3 * PROWS * W4, nh = PW - W;
+  const float inv_w4 = 1.0f / (float)W4, inv_nh = 1.0f / (float)nh;
+  for (int i = tid; i < 3 * PROWS * nh; i += 256) {                  // halo columns [0, XO) and [W + XO, PW)
+    const int row = (int)(((float)i + 0.5f) * inv_nh), k = i - row * nh;
+    patch[row * PW + (k < XO ? k : W + k)] = 0;
+  }
+  for (int base = tid; base < nitems; base += 256 * CH) {
+    f32x4 v[CH]; int dst[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int id = base + 256 * i;
+      dst[i] = -1;
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (id < nitems) {
+        const int row = (int)(((float)id + 0.5f) * inv_w4), j = id - row * W4;
+        const int c = row / PROWS, pr = row - c * PROWS, ih = ih_base + pr;
+        dst[i] = row * PW + 4 * j + XO;
+        if (ih >= 0 && ih < H)
+          v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsImg, (((b * 3 + c) * H + ih) * W + 4 * j) * 4, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (dst[i] < 0) continue;
+      bf16_t* d = patch + dst[i];
+      d[0] = f2bf(v[i][0]);
+      *reinterpret_cast<uint32_t*>(d + 1) = (uint32_t)f2bf(v[i][1]) | ((uint32_t)f2bf(v[i][2]) << 16);
+      d[3] = f2bf(v[i][3]);
+    }
+  }
+}
+
 // wstem[n][(c*7+r)*8+s] = w[n][r][s][c] (KRSC fp32 master), zero for s == 7 and pairs 21..23
 __global__ void stem_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,6 +177,145 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 
 
 // ------------------------------------------------------------------------------------------------
+// Inference stem: conv7x7/2 + BatchNorm (running statistics: scale / shift per channel) + ReLU + MaxPool3x3/2 p1 in ONE kernel
+// (models/cnn_backbone.py:349-354 in eval mode).  The 112 x 112 x 64 conv output -- 822 MB written and read back at B = 512 by the
+// two-kernel path -- never exists: a wave computes the conv tile of 16 columns for the THREE conv rows of a pooled row (24 MFMAs
+// each, operands as in stem_conv_kernel), applies scale / shift / ReLU to the fp32 accumulators and pools in registers.
+//   columns: tile t covers conv columns 14t-1 .. 14t+14, i.e. the windows of pooled columns 7t .. 7t+6.  In the accumulator layout
+//            a lane holds 4 consecutive columns p = 4g .. 4g+3 of one channel: pooled column 2g is the max of its p, p+1, p+2 and
+//            pooled column 2g+1 needs column 4g+4 from the lane 16 further on (one cross-lane move per channel tile).
+//   rows:    pooled row k of the block uses conv rows 2k, 2k+1, 2k+2 of the block's 2*PRB+1; the shared row is carried.
+//   padding: conv positions outside the image (column -1, row -1, columns >= Wo of a ragged last tile) are zeroed AFTER the ReLU,
+//            which is the identity of a max over non-negative values (MaxPool pads with -inf; every window holds a real position).
+// Redundant MFMA work (16 columns per 14, 9 rows per 8): 1.29x of a kernel that is HBM-bound by 4x.  No argmax: inference only.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int PRB = 4;               // pooled rows per workgroup
+constexpr int NCR = 2 * PRB + 1;     // conv rows per workgroup
+constexpr int PRP = 2 * NCR + 5;     // patch rows (23)
+}
+__device__ __forceinline__ float pool_max(float a, float b) { return (b > a || b != b) ? b : a; }     // NaN propagates (ATen max_pool2d)
+
+__global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wst,
+                                                                const float* __restrict__ coef, bf16_t* __restrict__ out,
+                                                                int B, int H, int W, int Ho, int Wo, int Hp, int Wp, int ctiles, int PW, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* patch = reinterpret_cast<bf16_t*>(smem);                 // [3][PRP][PW], x = iw + 5
+  bf16_t* Wl = patch + 3 * PRP * PW;                                // [64][LDW]
+  bf16_t* Cst = Wl;                                                 // [4 waves][8][LDCS] once the B fragments are in registers
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int pblocks = Hp / PRB;
+  const int b = blockIdx.x / pblocks, ph0 = (blockIdx.x - b * pblocks) * PRB;
+
+  for (int v = tid; v < 64 * (KP / 8); v += 256) {
+    const int n = v / (KP / 8), kv = v - n * (KP / 8);
+    *reinterpret_cast<u32x4*>(&Wl[n * LDW + kv * 8]) = *reinterpret_cast<const u32x4*>(&wst[n * KP + kv * 8]);
+  }
+  const int ih_base = 4 * ph0 - 5;                                   // input row of patch row 0: 2 * (2 * ph0 - 1) - 3
+  const __amdgpu_buffer_rsrc_t rsImg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, B * 3 * H * W * 4, 0x00020000);
+  if (dbg & 8) {}
+  else if (!(W & 3)) stem_fill_patch<PRP, 5, 8>(patch, PW, rsImg, b, ih_base, H, W, tid);
+  else
+  for (int x = tid; x < PW; x += 256) {
+    const int iw = x - 5;
+    const bool cok = iw >= 0 && iw < W;
+    const int iwc = min(max(iw, 0), W - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                                    // one channel's 23 rows in flight at a time
+      float vals[PRP];
+#pragma unroll
+      for (int pr = 0; pr < PRP; ++pr) {
+        const int ih = ih_base + pr;
+        const int ihc = min(max(ih, 0), H - 1);
+        const float t = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsImg, (((b * 3 + c) * H + ihc) * W + iwc) * 4, 0, 0));
+        vals[pr] = (cok && ih >= 0 && ih < H) ? t : 0.f;
+      }
+#pragma unroll
+      for (int pr = 0; pr < PRP; ++pr) patch[(c * PRP + pr) * PW + x] = f2bf(vals[pr]);
+    }
+  }
+  __syncthreads();
+  bf16x8 bfr[6][4];
+#pragma unroll
+  for (int kk = 0; kk < 6; ++kk)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      bfr[kk][nt] = *reinterpret_cast<const bf16x8*>(&Wl[(nt * 16 + li) * LDW + kk * 32 + g * 8]);
+  float sc[4], sh[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) { sc[nt] = coef[nt * 16 + li]; sh[nt] = coef[64 + nt * 16 + li]; }
+  __syncthreads();                                                   // Wl is dead: C staging may overwrite it
+  if (dbg & 4) { if (tid == 0) out[(size_t)blockIdx.x * 64] = f2bf(sc[0] + (float)bfr[0][0][0]); return; }
+
+  bf16_t* mycs = Cst + wave * 8 * LDCS;
+  for (int t = wave; t < ctiles; t += 4) {
+    const int c0 = 14 * t - 1;                                        // conv column of accumulator row p = 0
+    // conv row i of the block (conv row 2*ph0 - 1 + i) -> BN + ReLU -> horizontal 3-max at stride 2: h[nt][0] = pooled column 2g,
+    // h[nt][1] = pooled column 2g + 1 (garbage for g == 3: never stored)
+    auto row = [&](int i, float (&h)[4][2]) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!(dbg & 1))
+#pragma unroll
+      for (int kk = 0; kk < 6; ++kk) {
+        int pair = kk * 4 + g;
+        pair = pair > 20 ? 20 : pair;
+        const int c = pair / 7, r = pair - c * 7;
+        const uint32_t* ap = reinterpret_cast<const uint32_t*>(&patch[(c * PRP + 2 * i + r) * PW + 28 * t + 2 * li]);
+        u32x4 raw = {ap[0], ap[1], ap[2], ap[3]};
+        const bf16x8 af = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[kk][nt], acc[nt], 0, 0, 0);
+      }
+      if (dbg & 2) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { h[nt][0] = acc[nt][0] + acc[nt][1]; h[nt][1] = acc[nt][2] + acc[nt][3]; }
+        return;
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        float v[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int col = c0 + 4 * g + r4;
+          const float a = acc[nt][r4] * sc[nt] + sh[nt];
+          v[r4] = ((unsigned)col < (unsigned)Wo) ? (a < 0.f ? 0.f : a) : 0.f;
+        }
+        const float nx = __shfl_down(v[0], 16, 64);                   // column 4g + 4
+        h[nt][0] = pool_max(pool_max(v[0], v[1]), v[2]);
+        h[nt][1] = pool_max(pool_max(v[2], v[3]), nx);
+      }
+    };
+    float hp[4][2], h1[4][2], h2[4][2];
+    if (ph0 > 0) row(0, hp);                                          // conv row 2*ph0 - 1 (row -1 of the image: outside)
+    else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { hp[nt][0] = 0.f; hp[nt][1] = 0.f; }
+    }
+#pragma unroll 1
+    for (int k = 0; k < PRB; ++k) {
+      row(2 * k + 1, h1);
+      row(2 * k + 2, h2);
+      // this lane's two pooled columns x four channel tiles -> wave-private staging -> 16-byte row stores
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float o = pool_max(pool_max(hp[nt][q], h1[nt][q]), h2[nt][q]);
+          mycs[(2 * g + q) * LDCS + nt * 16 + li] = f2bf(o);
+          hp[nt][q] = h2[nt][q];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int px = lane >> 3, cv = lane & 7, pw = 7 * t + px;
+      if (px < 7 && pw < Wp)
+        *reinterpret_cast<u32x4*>(&out[((((size_t)b * Hp + ph0 + k) * Wp + pw) * 64) + cv * 8]) = *reinterpret_cast<const u32x4*>(&mycs[px * LDCS + cv * 8]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stem weight gradient: dW[n][(r,s,c)] += sum_pixels dy[pixel][n] * im2col(img)[pixel][(c,r,s8)]
 // Persistent workgroups walk (image, 2-output-row) blocks; per output row the im2col slice [pixels][192] is built in LDS
 // from the resident patch, dy's row is staged [pixels][64], and both MFMA operands are read with ds_read_b64_tr_b16
@@ -192,6 +375,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBW;
     __syncthreads();                                                 // previous block's readers are done with the patch
     const int ih_base = 2 * oh0 - 3;
+    // (scalar fill on purpose: with stem_fill_patch inlined here the fused kernel needs 171 instead of 118 registers, two workgroups per
+    //  CU instead of three, and the stem backward goes 709 -> 940 us)
     for (int x = tid; x < PW; x += 256) {
       const int iw = x - 3;
       const bool cok = iw >= 0 && iw < W;
@@ -342,6 +527,34 @@ int vqa_stem_conv(const float* img, const void* wstem, void* out, float* stats, 
   static size_t attr = 0;
   if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
   hipLaunchKernelGGL(stem_conv_kernel, dim3(nb), dim3(256), shm, st, img, (const bf16_t*)wstem, (bf16_t*)out, stats, H, W, Ho, Wo);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+
+// Inference stem in one launch (see stem_conv_pool_kernel).  bf16 only.  coef: scale[64] | shift[64] (vqa_bn_eval_coef); out: the
+// POOLED activation NHWC bf16 [B][Hp][Wp][64].  vqa_stem_conv_pool_ok: 1 when the shape is supported (even conv output, pooled rows
+// a multiple of 4, the workgroup's LDS within 160 KB).
+static size_t stem_conv_pool_shm(int H, int W, int* ctiles_out, int* pw_out) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1, Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+  if (H < 7 || W < 7 || (Ho & 1) || (Wo & 1) || Hp % PRB) return 0;
+  const int ctiles = (Wp + 6) / 7;
+  const int PW = (2 * (14 * ctiles + 2) + 8 + 7) / 8 * 8;            // x = 28 t + 2 li + 0..7 <= 28 (ctiles-1) + 37
+  if (ctiles_out) *ctiles_out = ctiles;
+  if (pw_out) *pw_out = PW;
+  const size_t shm = (size_t)(3 * PRP * PW + 64 * LDW) * 2;
+  return shm <= 160 * 1024 ? shm : 0;
+}
+int vqa_stem_conv_pool_ok(int B, int H, int W) {
+  return B > 0 && stem_conv_pool_shm(H, W, nullptr, nullptr) > 0 && (size_t)B * 3 * H * W * 4 < 0x7fffffffull;
+}
+int vqa_stem_conv_pool(const float* img, const void* wstem, const float* coef, void* out, int B, int H, int W, hipStream_t st) {
+  int ctiles = 0, PW = 0;
+  const size_t shm = stem_conv_pool_shm(H, W, &ctiles, &PW);
+  if (!img || !wstem || !coef || !out || !vqa_stem_conv_pool_ok(B, H, W)) return VQA_EARG;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1, Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+  static size_t attr = 0;
+  if (shm > attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = shm; }
+  hipLaunchKernelGGL(stem_conv_pool_kernel, dim3(B * (Hp / PRB)), dim3(256), shm, st, img, (const bf16_t*)wstem, coef, (bf16_t*)out,
+                     B, H, W, Ho, Wo, Hp, Wp, ctiles, PW, vqa_env_int("VQA_STEMCP_DBG", 0));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 

@@ -112,6 +112,7 @@ class HipEngine:
         # test hook (tests/test_gpu_insitu.py): a dict here receives, per residual block, the intermediate gradients of its backward
         # (dout, dy2, dyd, da1, dy1, dx) so that every layer of a LIVE full-size bf16 step can be checked locally against fp32 math
         self.capture = None
+        self.fuse_stem_eval = True                # inference (no tape): conv7x7 + BN + ReLU + MaxPool of the stem in one launch
         self.mark = None                          # measurement hook (tools/phase_times.py): called with a label at forward boundaries
 
     # ------------------------------------------------------------------ parameter access
@@ -482,16 +483,21 @@ class HipEngine:
         H1, W1 = (IH + 6 - 7) // 2 + 1, (IW + 6 - 7) // 2 + 1
         M = B * H1 * W1
         sgeom = (B, IH, IW, 3, H1, W1, 7, 7, 2, 3)
-        if self.stem_w2 is not None and K.stem_conv_blocks(B, IH, IW) > 0:
-            y, st, mt = K.stem_conv(images, self.stem_w2, B, IH, IW, training)
-        else:
-            y, st, mt = K.igemm(images, self.stem_w, M, 64, self.stem_kp, sgeom, dtype=T, loader=K.LOADER_STEM, want_stats=training)
-        coef = self._bn_coef("image_encoder.stem.1", st, mt, 64, M, training)
         Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
-        x = torch.empty((B * Hp * Wp, 64), device=dev, dtype=T)
-        idx = torch.empty((B * Hp * Wp, 64), device=dev, dtype=torch.uint8)
-        call("vqa_stem_pool_fwd", dt(T), ptr(y), ptr(coef), ptr(x), ptr(idx), B, H1, W1, 64)
-        tape["stem"] = dict(images=images, y=y, coef=coef, idx=idx, geom=sgeom, H1=H1, W1=W1)
+        x = None
+        if self.fuse_stem_eval and not training and not need_tape and self.stem_w2 is not None:
+            # inference: the whole stem in one launch, the 112 x 112 conv output is never stored (no argmax: there is no backward)
+            x = K.stem_conv_pool(images, self.stem_w2, self._bn_coef("image_encoder.stem.1", None, 0, 64, M, False), B, IH, IW)
+        if x is None:
+            if self.stem_w2 is not None and K.stem_conv_blocks(B, IH, IW) > 0:
+                y, st, mt = K.stem_conv(images, self.stem_w2, B, IH, IW, training)
+            else:
+                y, st, mt = K.igemm(images, self.stem_w, M, 64, self.stem_kp, sgeom, dtype=T, loader=K.LOADER_STEM, want_stats=training)
+            coef = self._bn_coef("image_encoder.stem.1", st, mt, 64, M, training)
+            x = torch.empty((B * Hp * Wp, 64), device=dev, dtype=T)
+            idx = torch.empty((B * Hp * Wp, 64), device=dev, dtype=torch.uint8)
+            call("vqa_stem_pool_fwd", dt(T), ptr(y), ptr(coef), ptr(x), ptr(idx), B, H1, W1, 64)
+            tape["stem"] = dict(images=images, y=y, coef=coef, idx=idx, geom=sgeom, H1=H1, W1=W1)
         H, W, C = Hp, Wp, 64
         # ---- text encoder, A6-A8 (on the side stream; joined before fusion).  Issued behind stage 1: by then the GPU holds > 1 ms of
         #      queued work, which covers the millisecond the host spends on these ~100 launches (see the stem note above).

@@ -251,6 +251,24 @@ def stem_conv(img, wstem, B, H, W, want_stats):
     return y, stats, nb
 
 
+def stem_conv_pool(img, wstem, coef, B, H, W):
+    """Inference stem in one launch: conv7x7/2 + BatchNorm (running statistics) + ReLU + MaxPool3x3/2 from the NCHW fp32 image.
+    Returns the pooled activation [B*Hp*Wp, 64] bf16, or None when the shape is not supported (the caller takes the two-kernel path)."""
+    if not L.count("vqa_stem_conv_pool_ok", B, H, W):
+        return None
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+    x = torch.empty((B * Hp * Wp, 64), device=img.device, dtype=torch.bfloat16)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_stem_conv_pool", ptr(img), ptr(wstem), ptr(coef), ptr(x), B, H, W)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("stem_conv_pool_kernel", 2.0 * B * Ho * Wo * 64 * 147, e0, e1, B * 3 * H * W * 4 + B * Hp * Wp * 64 * 2))
+    return x
+
+
 def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=None, addmask=None, outmask=None, want_stats=False,
           transposed=0, relu=0, drop_p=0.0, drop_seed=0, out=None, stats_acc=None):
     """out[M][N] = gather(a) @ w[N][Kw]^T with the fused epilogue.  geom = (B, H, W, C, Ho, Wo, R, S, stride, pad).
