@@ -91,3 +91,45 @@ def test_fused_stem_wgrad_matches_oracle_autograd_224(B):
     ref = sdr[wn].grad.permute(0, 2, 3, 1)
     assert _relerr(got, ref) < 0.15
     assert abs(float(got.norm()) - float(ref.norm())) / float(ref.norm()) < 2e-2
+
+
+@pytest.mark.parametrize("hw", [(224, 224), (384, 384), (96, 160)])
+def test_fused_stem_wgrad_equals_two_launch_path_per_shape(hw):
+    """Kernel level, at the shapes whose row split differs (224: 2 pieces per row; the 384 x 384 stress shape: 6 pieces so that three
+    workgroups share a CU; 96 x 160: 2 pieces of 40): vqa_stem_wgrad_fused against vqa_stem_bwd_apply + the generic weight
+    gradient on the same y / argmax / coefficients (the two-launch path rounds dy to bf16 first: 5e-3)."""
+    import torch.nn.functional as F
+    K, L = sub("kernels"), sub("_lib")
+    H, W = hw
+    B = 3
+    g = torch.Generator().manual_seed(H + 3 * W)
+    img = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, 7, 7, 3, generator=g) * 0.1).to(DEV)
+    wst = torch.empty(64, 192, device=DEV, dtype=torch.bfloat16)
+    L.call("vqa_stem_pack", w.data_ptr(), wst.data_ptr())
+    Ho, Wo = H // 2, W // 2
+    Hp, Wp = Ho // 2, Wo // 2
+    y, stats, nb = K.stem_conv(img, wst, B, H, W, True)
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.3).to(DEV)
+    rm, rv, nbt = torch.zeros(64, device=DEV), torch.ones(64, device=DEV), torch.zeros((), device=DEV, dtype=torch.int64)
+    coef = K.bn_train_coef(stats, nb, 64, B * Ho * Wo, gamma, beta, rm, rv, nbt)
+    x = torch.empty(B * Hp * Wp, 64, device=DEV, dtype=torch.bfloat16)
+    idx = torch.empty(B * Hp * Wp, 64, device=DEV, dtype=torch.uint8)
+    L.call("vqa_stem_pool_fwd", 1, y.data_ptr(), coef.data_ptr(), x.data_ptr(), idx.data_ptr(), B, Ho, Wo, 64)
+    dpool = torch.randn(B * Hp * Wp, 64, generator=g).to(DEV, torch.bfloat16)
+    bc = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.05, torch.randn(64, generator=g) * 0.01]).to(DEV)
+    dw1 = torch.zeros(64, 147, device=DEV)
+    ws, wsf = K.stem_wgrad_scratch(DEV, B, H, W)
+    L.call("vqa_stem_wgrad_fused", img.data_ptr(), y.data_ptr(), dpool.data_ptr(), idx.data_ptr(), coef.data_ptr(), bc.data_ptr(),
+           dw1.data_ptr(), B, H, W, ws.data_ptr(), wsf)
+    dy = torch.empty_like(y)
+    L.call("vqa_stem_bwd_apply", 1, dpool.data_ptr(), idx.data_ptr(), y.data_ptr(), coef.data_ptr(), bc.data_ptr(), dy.data_ptr(), B, Ho, Wo, 64)
+    dw2 = torch.zeros(64, 147, device=DEV)
+    K.wgrad(dy, img, dw2, B * Ho * Wo, 64, 147, (B, H, W, 3, Ho, Wo, 7, 7, 2, 3), dtype=torch.bfloat16, loader=K.LOADER_STEM)
+    torch.cuda.synchronize()
+    assert dw2.abs().max() > 0 and _relerr(dw1, dw2) < 5e-3
+    # and against ATen's conv weight gradient of the same (bf16-rounded) dy and image
+    wref = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    F.conv2d(img.cpu().to(torch.bfloat16).float(), wref, None, stride=2, padding=3).backward(
+        dy.float().cpu().view(B, Ho, Wo, 64).permute(0, 3, 1, 2).contiguous())
+    assert _relerr(dw1.cpu(), wref.grad.permute(0, 2, 3, 1).reshape(64, 147)) < 6e-3

@@ -487,22 +487,29 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 
 extern "C" int vqa_slab_reduce(const float* ws, float* dw, int nslabs, long long n, hipStream_t st);
 
-static int stem_wgrad_grid(int B, int Ho, int Wo, size_t* shm_out) {
-  int nsplit = Wo > 64 ? 2 : 1;
-  { const int env = vqa_env_int("VQA_STEM_NSPLIT", 0); if (env > 0 && Wo % (8 * env) == 0) nsplit = env; }
+// A row is contracted in nsplit pieces (Wo / nsplit pixels each, a multiple of 8).  The kernel is latency-bound in its staging phase
+// and lives off the co-resident workgroups: the smallest split whose LDS footprint lets THREE of them share a CU (224 x 224 images:
+// 2 pieces, 52 KB; the 384 x 384 stress shape: 6 pieces, 48 KB -- with the 2 pieces it used to get, 82 KB and ONE workgroup per CU,
+// the launch took 1.87 ms).
+static size_t stem_wgrad_shm(int Wo, int nsplit) {
   const int PW = 2 * Wo + 8, MP = (Wo / nsplit + 31) / 32 * 32;
-  const size_t shm = (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
+  return (size_t)(3 * PRW * PW + MP * LDA + MP * LDD) * 2;
+}
+static int stem_nsplit(int Wo) {
+  const int env = vqa_env_int("VQA_STEM_NSPLIT", 0);
+  if (env > 0 && Wo % (8 * env) == 0) return env;
+  const int floor_ = Wo > 64 ? 2 : 1;
+  for (int n = floor_; n <= 16; ++n)
+    if (Wo % (8 * n) == 0 && stem_wgrad_shm(Wo, n) <= (size_t)160 * 1024 / 3) return n;
+  return floor_;
+}
+static int stem_wgrad_grid(int B, int Ho, int Wo, size_t* shm_out) {
+  const size_t shm = stem_wgrad_shm(Wo, stem_nsplit(Wo));
   if (shm_out) *shm_out = shm;
   if (shm > 160 * 1024) return 0;
   const int nblocks = B * (Ho / RBW);
   const int cap = 256 * (int)((160 * 1024) / shm > 4 ? 4 : (160 * 1024) / shm);
   return nblocks < cap ? nblocks : cap;
-}
-
-static int stem_nsplit(int Wo) {
-  const int env = vqa_env_int("VQA_STEM_NSPLIT", 0);
-  if (env > 0 && Wo % (8 * env) == 0) return env;
-  return Wo > 64 ? 2 : 1;
 }
 
 extern "C" {
