@@ -20,6 +20,7 @@ def child(lib, extra):
         pkg._lib._lib = None
     import bench
     real = os.dup(1)
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)              # bench.py's own JSON line is not wanted here
     r = bench.main(["--no-cpu-baseline", "--no-extras"] + extra)
     os.write(real, (json.dumps({"ms": r["ms_per_step"], "frac": r["roofline"]["frac"], "dom_us": r["roofline"].get("avg_launch_us")}) + "\n").encode())
 
