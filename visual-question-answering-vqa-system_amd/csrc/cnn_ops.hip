@@ -641,13 +641,14 @@ __global__ __launch_bounds__(256) void scale_kernel(const T* __restrict__ x, con
 
 // SE backward, per sample: ds[c] = sum_hw dout*x ; through sigmoid / fc2 / relu / fc1 -> dz2[B][C], dh[B][Cr], dpool[B][C]
 template <typename T>
-__global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ w1,
+__global__ __launch_bounds__(1024) void se_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ w1,
                                                             const float* __restrict__ w2, const float* __restrict__ hidden,
                                                             const float* __restrict__ scale, float* __restrict__ dz2, float* __restrict__ dh,
                                                             float* __restrict__ dpool, int HW, int C, int Cr) {
   constexpr int VEC = Vec16<T>::N;
   extern __shared__ float sh[];
-  const int b = blockIdx.x, cv = C / VEC, lanes_r = 256 / cv;
+  const int NT = blockDim.x;                      // 256 ... 1024 threads per sample (vqa_se_bwd picks; both forms use the same count)
+  const int b = blockIdx.x, cv = C / VEC, lanes_r = NT / cv;
   const int myv = threadIdx.x % cv, myr = threadIdx.x / cv;
   float s[VEC];
 #pragma unroll
@@ -671,8 +672,8 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
   for (int j = 0; j < VEC; ++j) sh[threadIdx.x * VEC + j] = s[j];
   __syncthreads();
-  float* z2 = sh + 256 * VEC; float* dhs = z2 + C;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  float* z2 = sh + NT * VEC; float* dhs = z2 + C;
+  for (int c = threadIdx.x; c < C; c += NT) {
     const int v = c / VEC, j = c - v * VEC;
     float t = 0.f;
     for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
@@ -682,14 +683,14 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int jr = wave; jr < Cr; jr += 4) {
+  for (int jr = wave; jr < Cr; jr += NT >> 6) {
     float t = 0.f;
     for (int c = lane; c < C; c += 64) t += z2[c] * w2[(size_t)c * Cr + jr];
     t = wave_sum(t);
     if (lane == 0) { t = hidden[(size_t)b * Cr + jr] > 0.f ? t : 0.f; dhs[jr] = t; dh[(size_t)b * Cr + jr] = t; }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += NT) {
     float t = 0.f;
     for (int jr = 0; jr < Cr; ++jr) t += dhs[jr] * w1[(size_t)jr * C + c];
     dpool[(size_t)b * C + c] = t;
@@ -767,15 +768,18 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
 // just filled (L2 / Infinity Cache) instead of from HBM after the whole batch has streamed through twice.  Same arithmetic in the
 // same order per element as the two-launch form: dx is bit-identical.  BNRED as in se_bwd_apply_kernel (accumulator mode only).
 template <typename T, bool BNRED>
-__global__ __launch_bounds__(256) void se_bwd_fused_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ w1,
+__global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ w1,
                                                            const float* __restrict__ w2, const float* __restrict__ hidden,
                                                            const float* __restrict__ scale, float* __restrict__ dz2, float* __restrict__ dh,
                                                            float* __restrict__ dpool, T* __restrict__ dx, int HW, int C, int Cr, int mask_out,
                                                            const T* __restrict__ bn_y, const float* __restrict__ bn_coef,
                                                            unsigned long long* __restrict__ bn_facc) {
   constexpr int VEC = Vec16<T>::N;
-  extern __shared__ float sh[];            // [256*VEC] scratch | z2[C] | dhs[Cr] | dpl[C] | scl[C]
-  const int b = blockIdx.x, cv = C / VEC, lanes_r = 256 / cv;
+  extern __shared__ float sh[];            // [NT*VEC] scratch | z2[C] | dhs[Cr] | dpl[C] | scl[C]
+  const int NT = blockDim.x;               // 1024 threads per sample where the shape allows: one workgroup per sample is all the
+                                           // parallelism there is (B = 512 samples on 256 CUs), and with 256 threads the two streaming
+                                           // passes kept 8 waves per CU in flight: 3.3 TB/s against the 5 TB/s of the BatchNorm passes
+  const int b = blockIdx.x, cv = C / VEC, lanes_r = NT / cv;
   const int myv = threadIdx.x % cv, myr = threadIdx.x / cv, c0 = myv * VEC;
   const size_t base = (size_t)b * HW * C + c0;
   float s[VEC];
@@ -799,8 +803,8 @@ __global__ __launch_bounds__(256) void se_bwd_fused_kernel(const T* __restrict__
 #pragma unroll
   for (int j = 0; j < VEC; ++j) sh[threadIdx.x * VEC + j] = s[j];
   __syncthreads();
-  float* z2 = sh + 256 * VEC; float* dhs = z2 + C; float* dpl = dhs + Cr; float* scl = dpl + C;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  float* z2 = sh + NT * VEC; float* dhs = z2 + C; float* dpl = dhs + Cr; float* scl = dpl + C;
+  for (int c = threadIdx.x; c < C; c += NT) {
     const int v = c / VEC, j = c - v * VEC;
     float t = 0.f;
     for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
@@ -811,14 +815,14 @@ __global__ __launch_bounds__(256) void se_bwd_fused_kernel(const T* __restrict__
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int jr = wave; jr < Cr; jr += 4) {
+  for (int jr = wave; jr < Cr; jr += NT >> 6) {
     float t = 0.f;
     for (int c = lane; c < C; c += 64) t += z2[c] * w2[(size_t)c * Cr + jr];
     t = wave_sum(t);
     if (lane == 0) { t = hidden[(size_t)b * Cr + jr] > 0.f ? t : 0.f; dhs[jr] = t; dh[(size_t)b * Cr + jr] = t; }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += NT) {
     float t = 0.f;
     for (int jr = 0; jr < Cr; ++jr) t += dhs[jr] * w1[(size_t)jr * C + c];
     dpl[c] = t; dpool[(size_t)b * C + c] = t;
@@ -853,7 +857,7 @@ __global__ __launch_bounds__(256) void se_bwd_fused_kernel(const T* __restrict__
     for (int j = 0; j < VEC; ++j) { sh[threadIdx.x * VEC + j] = sg[j]; }
     __syncthreads();
     const int R = acc_replicas(C);
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += NT) {
       const int v = c / VEC, j = c - v * VEC;
       float t = 0.f;
       for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(256) void se_bwd_fused_kernel(const T* __restrict__
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { sh[threadIdx.x * VEC + j] = sx[j]; }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += NT) {
       const int v = c / VEC, j = c - v * VEC;
       float t = 0.f;
       for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
@@ -1261,10 +1265,12 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   if (C % VEC || C / VEC > 256 || 256 % (C / VEC)) return VQA_EARG;
   if ((bn_slab != nullptr) != (bn_y != nullptr) || (bn_slab != nullptr) != (bn_coef != nullptr)) return VQA_EARG;
   float* dz2 = scratch; float* dh = dz2 + (size_t)B * C; float* dpool = dh + (size_t)B * Cr;
-  const size_t shm = ((size_t)256 * VEC + C + Cr) * 4;
+  const int cvh = C / VEC;
+  const int nt = (1024 % cvh == 0 && (long long)HW * cvh >= 4096) ? 1024 : 256;      // threads per sample (tiny maps: 256 are plenty)
+  const size_t shm = ((size_t)nt * VEC + C + Cr) * 4;
   if (!bn_slab || bn_acc_mode) {             // one pass structure: reduce + apply per sample in the same workgroup
-    const size_t shm2 = ((size_t)256 * VEC + 3 * C + Cr) * 4;
-#define SE_FUSED(TT, R) hipLaunchKernelGGL((se_bwd_fused_kernel<TT, R>), dim3(B), dim3(256), shm2, st, (const TT*)dout, (const TT*)x, w1, w2, hidden, scale, \
+    const size_t shm2 = ((size_t)nt * VEC + 3 * C + Cr) * 4;
+#define SE_FUSED(TT, R) hipLaunchKernelGGL((se_bwd_fused_kernel<TT, R>), dim3(B), dim3(nt), shm2, st, (const TT*)dout, (const TT*)x, w1, w2, hidden, scale, \
     dz2, dh, dpool, (TT*)dx, HW, C, Cr, mask_out, (const TT*)bn_y, bn_coef, (unsigned long long*)bn_slab)
     if (dtype) { if (bn_slab) SE_FUSED(bf16_t, true); else SE_FUSED(bf16_t, false); }
     else { if (bn_slab) SE_FUSED(float, true); else SE_FUSED(float, false); }
@@ -1272,8 +1278,8 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
     hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 7) / 8), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
     VQA_LAUNCH_CHECK(); return VQA_OK;
   }
-  DT(hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, dim3(B), dim3(256), shm, st, (const float*)dout, (const float*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr),
-     hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, dim3(B), dim3(256), shm, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr));
+  DT(hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, dim3(B), dim3(nt), shm, st, (const float*)dout, (const float*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr),
+     hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, dim3(B), dim3(nt), shm, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr));
   const size_t npix = (size_t)B * HW;
   if (npix >= (1ull << 28)) return VQA_EARG;
   const int ag = bn_slab ? vqa_se_bwd_blocks(dtype, B, HW, C) : px_grid(npix, C, VEC);
