@@ -88,11 +88,11 @@ def test_torch_custom_ops_are_registered_with_fake_impl():
     M = pkg().load_dropin()
     m = M.VQAModel(seed=0, num_answers=37)
     schema = str(torch.ops.vqa_hip.vqa_forward.default._schema)
-    assert "Tensor images" in schema and "Tensor[] params" in schema
+    assert "Tensor images" in schema and "Tensor flat_params" in schema
     with FakeTensorMode(allow_non_fake_inputs=True):
         imgs = torch.empty(3, 3, 224, 224, device="cuda")
         ids = torch.empty(3, 20, dtype=torch.long, device="cuda")
-        out = torch.ops.vqa_hip.vqa_forward(imgs, ids, None, [], m._handle, False, False)
+        out = torch.ops.vqa_hip.vqa_forward(imgs, ids, None, torch.empty(8, device="cuda"), m._handle, False, False)
         assert tuple(out.shape) == (3, 37) and out.dtype == torch.float32
         g = torch.ops.vqa_hip.vqa_backward(out, m._handle, 0)
         assert g.numel() == m._flat.numel()

@@ -41,8 +41,11 @@ _NEXT_HANDLE = [1]
 
 
 @torch.library.custom_op("vqa_hip::vqa_forward", mutates_args=(), device_types="cuda")
-def _vqa_forward_op(images: torch.Tensor, token_ids: torch.Tensor, mask: Optional[torch.Tensor], params: List[torch.Tensor],
+def _vqa_forward_op(images: torch.Tensor, token_ids: torch.Tensor, mask: Optional[torch.Tensor], flat_params: torch.Tensor,
                     handle: int, training: bool, want_aux: bool) -> torch.Tensor:
+    # flat_params: the model's ONE flat fp32 parameter buffer as an autograd-tracked alias (_FlatParams below).  Handing the dispatcher
+    # the 164 parameter views as a List[Tensor] cost ~0.6 ms of host time per call before the first kernel went out -- idle GPU time
+    # for a caller that synchronises every step (training/train.py:211)
     model = _MODELS[handle]
     logits, aux, tape = model._engine.forward(images, token_ids, mask, training, want_aux, need_tape=True)
     model._last_aux = aux              # aux tensors are detached by construction (side channel, not graph outputs)
@@ -54,7 +57,7 @@ def _vqa_forward_op(images: torch.Tensor, token_ids: torch.Tensor, mask: Optiona
 
 
 @_vqa_forward_op.register_fake
-def _(images, token_ids, mask, params, handle, training, want_aux):
+def _(images, token_ids, mask, flat_params, handle, training, want_aux):
     return images.new_empty((images.shape[0], _MODELS[handle].num_answers), dtype=torch.float32)
 
 
@@ -84,13 +87,28 @@ def _setup_ctx(ctx, inputs, output):
 
 
 def _backward(ctx, dlogits):
-    model = _MODELS[ctx.handle]
     G = torch.ops.vqa_hip.vqa_backward(dlogits, ctx.handle, ctx.tape_id)
-    lay = model._pkg.layout
-    return None, None, None, [lay.view_of(G, e) for e in model._param_entries], None, None, None
+    return None, None, None, G, None, None, None
 
 
 torch.library.register_autograd("vqa_hip::vqa_forward", _backward, setup_context=_setup_ctx)
+
+
+class _FlatParams(torch.autograd.Function):
+    """The flat parameter buffer as a function of the 164 leaf Parameters that are views into it: forward aliases the buffer (no
+    copy), backward hands each Parameter its slice of the flat gradient (views of ONE tensor, as `.grad` wants them for the flat
+    optimizer paths).  A plain autograd.Function with 164 inputs costs ~0.15 ms of host time; the custom op behind it takes one tensor."""
+
+    @staticmethod
+    def forward(ctx, flat, handle, *params):
+        ctx.handle = handle
+        return flat.detach()
+
+    @staticmethod
+    def backward(ctx, G):
+        model = _MODELS[ctx.handle]
+        lay = model._pkg.layout
+        return (None, None) + tuple(lay.view_of(G, e) for e in model._param_entries)
 
 
 class VQAModel(nn.Module):
@@ -152,7 +170,13 @@ class VQAModel(nn.Module):
         _MODELS[self._handle] = self
 
     def _param_list(self):
-        return [getattr_path(self, e.name) for e in self._param_entries]
+        # the 164 Parameter objects never change identity (.to() only swaps their .data), but resolving 164 dotted names through
+        # nn.Module.__getattr__ on every forward cost the unchanged train.py loop a few hundred host microseconds with the GPU idle
+        pl = self.__dict__.get("_params_cache")
+        if pl is None:
+            pl = [getattr_path(self, e.name) for e in self._param_entries]
+            self.__dict__["_params_cache"] = pl
+        return pl
 
     def __del__(self):
         _MODELS.pop(getattr(self, "_handle", -1), None)
@@ -199,7 +223,8 @@ class VQAModel(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             # tapes are kept by id (gradient accumulation / loss1 + loss2: several forwards, then their backwards), oldest dropped
             # beyond max_live_tapes
-            logits = torch.ops.vqa_hip.vqa_forward(images, token_ids, maskf, params, self._handle, self.training, return_aux)
+            flat = _FlatParams.apply(self._flat, self._handle, *params)
+            logits = torch.ops.vqa_hip.vqa_forward(images, token_ids, maskf, flat, self._handle, self.training, return_aux)
             aux, self._last_aux = self._last_aux, None
         elif (self.graph_inference and not self.training and not return_aux and 0 < images.shape[0] <= self.graph_max_batch
               and not torch.cuda.is_current_stream_capturing()):
