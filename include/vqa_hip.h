@@ -64,6 +64,19 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
 int vqa_conv3x3_c64p_blocks(int B, int H, int W);
 int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W,
                      int stats_mode /* 1: stats is the fixed-point accumulator u64 [2*64 + 1] of vqa_bn_apply_acc */, hipStream_t stream);
+/* Round 4 -- training-mode "Conv3x3 + BN + ReLU" without the normalised tensor (models/cnn_backbone.py:182-187: conv1 -> bn1 -> relu ->
+ * conv2 at 64 channels).  vqa_conv3x3_c64p_bn is vqa_conv3x3_c64p applied to relu(BatchNorm(y)): y = the previous conv's raw output,
+ * acc = its fixed-point statistics (the launch that wrote y ran with stats_mode = 1).  Every workgroup finalizes the 64 coefficients in
+ * its prologue, workgroup 0 publishes coef_out[4][64] (scale | shift | mean | invstd) and updates the running statistics (what
+ * vqa_bn_apply_acc does), and each input patch is normalised + ReLU'd IN LDS after its DMA landed -- zero padding stays zero; the conv
+ * result is bit-identical to vqa_conv3x3_c64p(vqa_bn_apply_acc(y)).  vqa_wgrad3x3_c64_bn is the matching weight gradient
+ * dw += dy^T gather(relu(y * coef[c] + coef[64 + c])) on the 8-wave kernel (vqa_wgrad3x3_c64_bn_ok: 1 when it takes the shape). */
+int vqa_conv3x3_c64p_bn(const void* y, const unsigned long long* acc, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, long long* num_batches_tracked, float* coef_out, const void* w, void* out, float* stats,
+                        int B, int H, int W, int stats_mode, double count, float momentum, float eps, hipStream_t stream);
+int vqa_wgrad3x3_c64_bn_ok(int B, int H, int W);
+int vqa_wgrad3x3_c64_bn(const void* y, const float* coef, const void* dy, float* dw /* [64][576] += */, int B, int H, int W,
+                        float* ws /* vqa_wgrad3x3_c64_blocks * 64*576 floats */, long long ws_floats, hipStream_t stream);
 /* stage-2 weight gradient (3x3 / 1 / pad 1, 128 -> 128 channels, 28 x 28 maps, bf16; models/cnn_backbone.py:182-187 backward): 8-wave
    LDS-DMA kernel + fixed-order slab reduce.  vqa_wgrad3x3_c128_blocks: slabs of 128*576 floats the workspace must hold, 0 = shape not
    supported (the caller uses vqa_wgrad). */
@@ -120,12 +133,12 @@ int vqa_bn_apply_pool_chunks(int dtype, int HW, int C);
 int vqa_bn_apply_pool(int dtype, const void* y, const float* coef, const void* res, const float* rcoef, void* out, int B, int HW, int C,
                       int relu, float* part, hipStream_t stream);
 /* Fixed-point statistics (round 3).  A producer launched with stats_mode = 1 (vqa_igemm, vqa_conv3x3_c64p) adds its per-workgroup
-   fp32 partial sums  sum y | sum y^2  to acc[vqa_bn_acc_words(2, C)] (unsigned 64-bit, scaled by 2^24, caller-zeroed; the last used
-   word counts partials that were non-finite / out of range -> NaN statistics) with integer atomics: order-independent, hence bit-reproducible, and complete
+   fp32 partial sums  sum y | sum y^2  to acc[vqa_bn_acc_words(2, C)] (unsigned 64-bit, each sum split exactly into a 2^-4 plane and a 2^-50 plane, caller-zeroed; the flag
+   word between the planes counts partials that were non-finite or beyond 2^41 -> NaN statistics; the total cannot wrap, csrc/common.h) with integer atomics: order-independent, hence bit-reproducible, and complete
    when the producer ends.  vqa_bn_apply_acc then does finalize (fp64, nn.BatchNorm2d training formulas, running-statistics update,
    coef_out [4][C] = scale | shift | mean | invstd for the backward) + apply (+ res | + BatchNorm(res) from racc, + ReLU) in ONE
    launch -- the finalize launches between conv and apply are gone.  pool_part != NULL: also the SE pooling sums (vqa_bn_apply_pool).
-   Backward: vqa_bn_bwd_reduce(acc_mode = 1) / vqa_se_bwd(bn_acc_mode = 1) add  sum g | sum g*xhat | sum g*xhat2  (scaled 2^40) to
+   Backward: vqa_bn_bwd_reduce(acc_mode = 1) / vqa_se_bwd(bn_acc_mode = 1) add  sum g | sum g*xhat | sum g*xhat2  (same format) to
    facc[vqa_bn_acc_words(3, C)]; vqa_bn_bwd_apply_acc derives the apply coefficients in its prologue and adds d gamma / d beta. */
 int vqa_bn_acc_words(int K, int C);   /* 64-bit words of an accumulator for K sums x C channels: R = clamp(512/C, 1, 8) replicas
                                          (same-address atomics are serialised, ~21 ns each) + the flag word; K = 2 forward, 3 backward */
@@ -162,8 +175,10 @@ int vqa_se_fwd(int dtype, const void* x, const float* w1, const float* w2, float
    its backward column sums sum dx | sum dx*xhat(bn_y) are written to bn_slab[vqa_se_bwd_blocks()][3][C] (the layout
    vqa_bn_bwd_finalize reads) in the same pass, so the caller skips vqa_bn_bwd_reduce for that BatchNorm */
 int vqa_se_bwd_blocks(int dtype, int B, int HW, int C);
+long long vqa_se_bwd_scratch(int dtype, int B, int HW, int C, int Cr);   /* floats of `scratch` below */
+/* bn_acc_mode 1: bn_slab is the u64 fixed-point accumulator (vqa_bn_acc_words(3, C)) instead of a float slab */
 int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, const float* w2, const float* pooled,
-               const float* hidden, const float* scale, float* scratch /* B*(2C+Cr) */, void* dx, float* dw1, float* dw2,
+               const float* hidden, const float* scale, float* scratch /* vqa_se_bwd_scratch() floats */, void* dx, float* dw1, float* dw2,
                int B, int HW, int C, int Cr, int mask_out /* dx *= (x > 0): x is a post-ReLU activation */,
                const void* bn_y, const float* bn_coef, float* bn_slab /* or the u64 accumulator when bn_acc_mode = 1 */, int bn_acc_mode,
                hipStream_t stream);
@@ -240,11 +255,14 @@ int vqa_cross_entropy(int dtype, const void* logits, const long long* targets, f
 int vqa_convert(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
 /* clip_grad_norm_(max_norm) + AdamW over flat fp32 buffers (training/train.py:204-208,127-132).
    skip (device int, may be NULL): when skip[0] != 0 the launch changes NOTHING (parameters, moments) and adds skip[0] to
-   skipped[0] and 1 to skipped[1] (device int[2], may be NULL) -- a step whose CrossEntropy saw an out-of-range target raises in
-   the reference before optimizer.step(), so the model must survive it. */
+   skipped[0], 1 to skipped[1] and 1 to skipped[2] (device int[3], may be NULL; [0] / [1] are the caller's to reset, [2] never) -- a
+   step whose CrossEntropy saw an out-of-range target raises in the reference before optimizer.step(), so the model must survive it.
+   calls: how many times the caller has launched vqa_adamw on this state, this launch included (>= 1).  Adam's step number
+   t = calls - skipped[2] is formed ON THE DEVICE (bias corrections 1 - beta^t in double, like torch.optim.AdamW), so a skipped launch
+   never advances it, whatever the host knows. */
 int vqa_sumsq(const float* g, long long n, float* out /* >= 2049 floats: [0] result (bit-reproducible), rest scratch */, hipStream_t stream);
 int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
-              float weight_decay, float bias_corr1, float bias_corr2, const float* sumsq, float max_norm, float gscale,
+              float weight_decay, long long calls, const float* sumsq, float max_norm, float gscale,
               const int* skip, int* skipped, hipStream_t stream);
 
 /* ---- input pipeline on the GPU -----------------------------------------------------------------

@@ -35,7 +35,6 @@ _STEP = textwrap.dedent("""
         answers = torch.randint(0, 100, (8,), device=device)
         losses = []
         model.train()
-        p0 = model.answer_head.classifier[6].weight.detach().clone() if hasattr(model.answer_head, "classifier") else None
         first = next(iter(model.parameters())).detach().clone()
         for _ in range(3):
             optimizer.zero_grad()

@@ -7,7 +7,7 @@ import bench
 pkg = importlib.import_module("visual-question-answering-vqa-system_amd")
 M = pkg.load_dropin()
 data = bench.synth_batch(512, torch.device("cuda", 0), 1234)
-CASES = [("default", {}), ("no bn_finalize fusion", dict(fuse_bn_finalize=False)), ("no se_pool", dict(fuse_se_pool=False)),
+CASES = [("default", {}), ("no fuse_bn_conv (a1 stored)", dict(fuse_bn_conv=False)), ("no bn_finalize fusion", dict(fuse_bn_finalize=False)), ("no se_pool", dict(fuse_se_pool=False)),
          ("no se_bnred", dict(fuse_se_bnred=False)), ("none of the three", dict(fuse_se_pool=False, fuse_se_bnred=False, fuse_bn_finalize=False))]
 NC = int(os.environ.get("AB_CASES", "4"))
 for rep in range(int(os.environ.get("AB_REPS", "2"))):
@@ -29,7 +29,7 @@ for rep in range(int(os.environ.get("AB_REPS", "2"))):
         torch.cuda.synchronize()
         st1 = torch.cuda.memory_stats()
         host.sort()
-        print(f"{tag:24s} {(time.perf_counter() - t0) / 30 * 1e3:7.3f} ms/step   host median {host[len(host)//2]*1e3:6.2f} max {host[-1]*1e3:6.2f}  "
+        print(f"{tag:28s} {(time.perf_counter() - t0) / 30 * 1e3:7.3f} ms/step   host median {host[len(host)//2]*1e3:6.2f} max {host[-1]*1e3:6.2f}  "
               f"device allocs +{st1['num_device_alloc'] - st0['num_device_alloc']} frees +{st1['num_device_free'] - st0['num_device_free']} "
               f"retries +{st1['num_alloc_retries'] - st0['num_alloc_retries']} reserved {st1['reserved_bytes.all.current'] / 2**30:.1f} GiB", flush=True)
         del tr, model

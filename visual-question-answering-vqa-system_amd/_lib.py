@@ -30,6 +30,9 @@ SIGNATURES = {
     "vqa_conv3x3_c64": [P, P, P, P, P, P, I, I, I, P],
     "vqa_conv3x3_c64p_blocks": [I, I, I],
     "vqa_conv3x3_c64p": [P, P, P, P, I, I, I, I, P],
+    "vqa_conv3x3_c64p_bn": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, D, F, F, P],
+    "vqa_wgrad3x3_c64_bn_ok": [I, I, I],
+    "vqa_wgrad3x3_c64_bn": [P, P, P, P, I, I, I, P, LL, P],
     "vqa_wgrad3x3_c128_blocks": [I, I, I],
     "vqa_wgrad3x3_c128": [P, P, P, I, I, I, P, LL, P],
     "vqa_wgrad3x3_c64_blocks": [I, I, I],
@@ -52,6 +55,7 @@ SIGNATURES = {
     "vqa_bn_apply_pool_chunks": [I, I, I],
     "vqa_bn_apply_pool": [I, P, P, P, P, P, I, I, I, I, P, P],
     "vqa_se_bwd_blocks": [I, I, I, I],
+    "vqa_se_bwd_scratch": [I, I, I, I, I],
     "vqa_bn_bwd_blocks": [LL],
     "vqa_bn_bwd_reduce": [I, P, P, P, P, P, P, P, LL, I, I, I, P],
     "vqa_bn_acc_words": [I, I],
@@ -97,10 +101,10 @@ SIGNATURES = {
     "vqa_image_resize_ws": [I, P, P, I, I, I],
     "vqa_image_resize": [P, P, P, P, P, I, I, I, I, I, P, P, P, F, F, F, F, F, F, P, LL, P],
     "vqa_pack_tokens": [P, P, P, P, I, I, I, I, I, I, P],
-    "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, F, F, P, F, F, P, P, P],
+    "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, LL, P, F, F, P, P, P],
 }
-_RET_LL = {"vqa_image_resize_ws", "vqa_wgrad_group_ws", "vqa_spatial_bwd_scratch", "vqa_layernorm_bwd_ws", "vqa_bias_act_bwd_ws"}                       # return a size (long long)
-_NO_STATUS = _RET_LL | {"vqa_wgrad3x3_c64_blocks", "vqa_bn_acc_words", "vqa_bn_apply_pool_chunks", "vqa_se_bwd_blocks", "vqa_wgrad3x3_c128_blocks", "vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks", "vqa_stem_conv_pool_ok"}   # return a count, not a status
+_RET_LL = {"vqa_image_resize_ws", "vqa_wgrad_group_ws", "vqa_spatial_bwd_scratch", "vqa_se_bwd_scratch", "vqa_layernorm_bwd_ws", "vqa_bias_act_bwd_ws"}                       # return a size (long long)
+_NO_STATUS = _RET_LL | {"vqa_wgrad3x3_c64_blocks", "vqa_bn_acc_words", "vqa_bn_apply_pool_chunks", "vqa_se_bwd_blocks", "vqa_wgrad3x3_c128_blocks", "vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks", "vqa_stem_conv_pool_ok", "vqa_wgrad3x3_c64_bn_ok"}   # return a count, not a status
 
 _lib = None
 

@@ -161,31 +161,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const T* __restrict_
 // kernel's epilogue): every thread finalizes the coefficients of ITS channels in the prologue (fp64, same formulas as
 // bn_finalize_kernel), the first workgroup also publishes coef[4][C] (scale | shift | mean | invstd: the backward reads it) and
 // updates running_mean / running_var / num_batches_tracked (nn.BatchNorm2d defaults).  No finalize launch in between.
-struct BnAcc {
-  const unsigned long long* acc; const float* gamma; const float* beta; float* rm; float* rv; long long* nbt; float* coef;
-};
-// One evaluation per channel and workgroup (the results are shared through LDS), fp64 only for the cancellation-prone
-// var = E[y^2] - mean^2; 1/count arrives precomputed and 1/sqrt is the fp32 hardware instruction -- a first version that divided
-// and took square roots in fp64 in every thread cost 3x the streaming work of the kernel.
-__device__ __forceinline__ void bn_acc_coef(const BnAcc& f, int C, int c, double inv_count, double unbias, float momentum, float eps, bool writer,
-                                            float& sc, float& sh) {
-  const int R = acc_replicas(C);
-  const double s = acc_read_fixed<VQA_ACC_FWD_SHIFT>(f.acc, R, 2, C, 0, c), q = acc_read_fixed<VQA_ACC_FWD_SHIFT>(f.acc, R, 2, C, 1, c);
-  double mean = s * inv_count;
-  double var = q * inv_count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  if (f.acc[(size_t)R * 2 * C] != 0) mean = __builtin_nan("");                 // a partial sum left the fixed-point range / was not finite
-  const float invstd = rsqrtf((float)var + eps);
-  sc = f.gamma[c] * invstd; sh = f.beta[c] - (float)mean * sc;
-  if (writer) {
-    f.coef[c] = sc; f.coef[C + c] = sh; f.coef[2 * C + c] = (float)mean; f.coef[3 * C + c] = invstd;
-    if (f.rm) {
-      f.rm[c] = (1.f - momentum) * f.rm[c] + momentum * (float)mean;
-      f.rv[c] = (1.f - momentum) * f.rv[c] + momentum * (float)(var * unbias);
-      if (c == 0 && f.nbt) *f.nbt += 1;
-    }
-  }
-}
+// (BnAcc / bn_acc_coef: common.h -- shared with the stage-1 patch kernels, which finalize the statistics of their INPUT's BatchNorm)
 // RES: 0 none, 1 + res, 2 + BatchNorm(res) with its own accumulators.  POOL: grid (chunks, B), SE pooling sums to part (see above).
 template <typename T, int RES, bool POOL>
 __global__ __launch_bounds__(256) void bn_apply_acc_kernel(const T* __restrict__ y, BnAcc f, const T* __restrict__ res, BnAcc fr,
@@ -290,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     for (int r = 0; r < lanes_r; ++r) s += shm[(k * 256 + r * cv + v) * VEC + j];
     if (facc) {                               // fixed point: order-free, no finalize launch; replica blockIdx.x % R
       const int R = acc_replicas(C);
-      if (k < 2 || DUAL) acc_add_fixed<VQA_ACC_BWD_SHIFT>(facc + ((size_t)(blockIdx.x % R) * 3 + k) * C + c, s, facc + (size_t)R * 3 * C);
+      if (k < 2 || DUAL) acc_add_fixed(facc, (size_t)R * 3 * C, ((size_t)(blockIdx.x % R) * 3 + k) * C + c, s);
     }
     else slab[((size_t)blockIdx.x * 3 + k) * C + c] = s;
   }
@@ -379,17 +355,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const T* __restri
   const int c0 = (threadIdx.x % cv) * VEC, myr = threadIdx.x / cv;
   const bool writer = blockIdx.x == 0;
   const int R = acc_replicas(C);
-  const bool bad = facc[(size_t)R * 3 * C] != 0;
+  const bool bad = acc_flagged(facc, R, 3, C);
   extern __shared__ float cf[];                // [3 | 6][C]: A, B, C (, A2, B2, C2): one evaluation per channel and workgroup
   for (int ch = threadIdx.x; ch < C; ch += 256) {
-    double sg = acc_read_fixed<VQA_ACC_BWD_SHIFT>(facc, R, 3, C, 0, ch), sx = acc_read_fixed<VQA_ACC_BWD_SHIFT>(facc, R, 3, C, 1, ch);
+    double sg = acc_read_fixed(facc, R, 3, C, 0, ch), sx = acc_read_fixed(facc, R, 3, C, 1, ch);
     if (bad) sg = sx = __builtin_nan("");
     const float mean = coef[2 * C + ch], invstd = coef[3 * C + ch], gi = gamma[ch] * invstd;
     const float mg = (float)(sg * inv_count), mgx = (float)(sx * inv_count);
     cf[ch] = gi; cf[C + ch] = -gi * invstd * mgx; cf[2 * C + ch] = gi * (mean * invstd * mgx - mg);
     if (writer) { dgamma[ch] += (float)sx; dbeta[ch] += (float)sg; }
     if (DUAL) {
-      double sx2 = acc_read_fixed<VQA_ACC_BWD_SHIFT>(facc, R, 3, C, 2, ch);
+      double sx2 = acc_read_fixed(facc, R, 3, C, 2, ch);
       if (bad) sx2 = __builtin_nan("");
       const float mean2 = coef2[2 * C + ch], inv2 = coef2[3 * C + ch], gi2 = gamma2[ch] * inv2, mgx2 = (float)(sx2 * inv_count);
       cf[3 * C + ch] = gi2; cf[4 * C + ch] = -gi2 * inv2 * mgx2; cf[5 * C + ch] = gi2 * (mean2 * inv2 * mgx2 - mg);
@@ -756,7 +732,7 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
       if (k < 2) for (int r = 0; r < lanes_r; ++r) t += shm[(k * 256 + r * cv + v) * VEC + j];
       if (bn_facc) {
         const int R = acc_replicas(C);
-        if (k < 2) acc_add_fixed<VQA_ACC_BWD_SHIFT>(bn_facc + ((size_t)(blockIdx.x % R) * 3 + k) * C + c, t, bn_facc + (size_t)R * 3 * C);
+        if (k < 2) acc_add_fixed(bn_facc, (size_t)R * 3 * C, ((size_t)(blockIdx.x % R) * 3 + k) * C + c, t);
       }
       else bn_slab[((size_t)blockIdx.x * 3 + k) * C + c] = t;
     }
@@ -861,7 +837,7 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
       const int v = c / VEC, j = c - v * VEC;
       float t = 0.f;
       for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
-      acc_add_fixed<VQA_ACC_BWD_SHIFT>(bn_facc + ((size_t)(blockIdx.x % R) * 3 + 0) * C + c, t, bn_facc + (size_t)R * 3 * C);
+      acc_add_fixed(bn_facc, (size_t)R * 3 * C, ((size_t)(blockIdx.x % R) * 3 + 0) * C + c, t);
     }
     __syncthreads();
 #pragma unroll
@@ -871,11 +847,16 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
       const int v = c / VEC, j = c - v * VEC;
       float t = 0.f;
       for (int r = 0; r < lanes_r; ++r) t += sh[(r * cv + v) * VEC + j];
-      acc_add_fixed<VQA_ACC_BWD_SHIFT>(bn_facc + ((size_t)(blockIdx.x % R) * 3 + 1) * C + c, t, bn_facc + (size_t)R * 3 * C);
+      acc_add_fixed(bn_facc, (size_t)R * 3 * C, ((size_t)(blockIdx.x % R) * 3 + 1) * C + c, t);
     }
   }
 }
 
+// (Round 4: a SPLIT form -- per-chunk column sums over a (row chunk, sample) grid, then fold + FC backward + apply per workgroup --
+// was built to give this pass more parallelism and measured SLOWER in isolation at every stage: 250 / 129 / 77 / 89 us against
+// 222 / 110 / 69 / 85 us for this kernel at B = 512 (tools/bench_hbm_kernels.py).  The one-workgroup-per-sample kernel is not short of
+// parallelism: it moves 6 tensor passes (r dout x | r dout x y2, w dx) at 5.5 TB/s; the "3.0 TB/s" of the bench line divides the FOUR
+// algorithmic passes by its time, i.e. it prices the second read of dout / x as a cache hit, which 512 x 0.8 MB in flight are not.)
 // dw2[c][j] += sum_b dz2[b][c]*hidden[b][j] ; dw1[j][c] += sum_b dh[b][j]*pooled[b][c]
 // A workgroup owns 8 consecutive (j, c) pairs (c fastest) and splits the batch over 32 thread slices; the slices are folded in LDS
 // in slice order, so every weight has ONE writer and a fixed summation order (bit-reproducible, no atomics, no scratch).
@@ -1109,7 +1090,7 @@ int vqa_bn_apply_pool(int dtype, const void* y, const float* coef, const void* r
 // with stats_mode = 1): finalize + running-statistics update + apply (+ residual | + BatchNorm(res) from racc, + ReLU) in ONE launch;
 // coef_out / rcoef_out [4][C] are published for the backward.  pool_part != NULL: the SE-pooling variant (vqa_bn_apply_pool).
 // 64-bit words of a fixed-point accumulator for K sums of C channels (replicas + flag, even): what the caller zeroes and passes
-int vqa_bn_acc_words(int K, int C) { const long long w = (long long)acc_replicas(C) * K * C + 1; return (int)((w + 1) / 2 * 2); }
+int vqa_bn_acc_words(int K, int C) { const long long w = 2ll * acc_replicas(C) * K * C + 1; return (int)((w + 1) / 2 * 2); }   // hi plane | flag | lo plane (common.h)
 int vqa_bn_apply_acc(int dtype, const void* y, const unsigned long long* acc, const float* gamma, const float* beta, float* rm, float* rv,
                      long long* nbt, float* coef_out, const void* res, const unsigned long long* racc, const float* rgamma, const float* rbeta,
                      float* rrm, float* rrv, long long* rnbt, float* rcoef_out, void* out, int B, int HW, int C, int relu, double count,
@@ -1255,9 +1236,12 @@ int vqa_se_bwd_blocks(int dtype, int B, int HW, int C) {
   const int g = px_grid((size_t)B * HW, C, VEC);
   return g > 2048 ? 2048 : g;          // slab rows vqa_bn_bwd_finalize folds (it is sized for <= ~1k rows: 16384 rows cost it +90 us)
 }
-// scratch: dz2[B*C] | dh[B*Cr] | dpool[B*C] floats
+// scratch floats vqa_se_bwd needs: dz2[B*C] | dh[B*Cr] | dpool[B*C]
+long long vqa_se_bwd_scratch(int dtype, int B, int HW, int C, int Cr) { (void)dtype; (void)HW; return (long long)B * (2 * C + Cr); }
+// scratch: vqa_se_bwd_scratch floats
 // bn_y / bn_coef / bn_slab (all or none): dx is the gradient entering the BatchNorm whose conv output is bn_y (the last block's bn2,
 // mask_out = 1): its backward column sums go to bn_slab[vqa_se_bwd_blocks][3][C] and vqa_bn_bwd_reduce is skipped by the caller.
+// bn_acc_mode: 1: bn_slab is a fixed-point accumulator (vqa_bn_acc_words(3, C))
 int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, const float* w2, const float* pooled, const float* hidden,
                const float* scale, float* scratch, void* dx, float* dw1, float* dw2, int B, int HW, int C, int Cr, int mask_out,
                const void* bn_y, const float* bn_coef, float* bn_slab, int bn_acc_mode, hipStream_t st) {
@@ -1268,7 +1252,9 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   const int cvh = C / VEC;
   const int nt = (1024 % cvh == 0 && (long long)HW * cvh >= 4096) ? 1024 : 256;      // threads per sample (tiny maps: 256 are plenty)
   const size_t shm = ((size_t)nt * VEC + C + Cr) * 4;
-  if (!bn_slab || bn_acc_mode) {             // one pass structure: reduce + apply per sample in the same workgroup
+  const bool accm = (bn_acc_mode & 1) != 0;
+  if (bn_slab && accm && B > VQA_ACC_MAX_PARTS) return VQA_EARG;     // one partial per sample (common.h: the fixed-point total must not wrap)
+  if (!bn_slab || accm) {                    // one pass structure: reduce + apply per sample in the same workgroup
     const size_t shm2 = ((size_t)nt * VEC + 3 * C + Cr) * 4;
 #define SE_FUSED(TT, R) hipLaunchKernelGGL((se_bwd_fused_kernel<TT, R>), dim3(B), dim3(nt), shm2, st, (const TT*)dout, (const TT*)x, w1, w2, hidden, scale, \
     dz2, dh, dpool, (TT*)dx, HW, C, Cr, mask_out, (const TT*)bn_y, bn_coef, (unsigned long long*)bn_slab)
@@ -1284,8 +1270,8 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   if (npix >= (1ull << 28)) return VQA_EARG;
   const int ag = bn_slab ? vqa_se_bwd_blocks(dtype, B, HW, C) : px_grid(npix, C, VEC);
 #define SE_APPLY(TT, R) hipLaunchKernelGGL((se_bwd_apply_kernel<TT, R>), dim3(ag), dim3(256), 0, st, (const TT*)dout, scale, dpool, (TT*)dx, (unsigned)npix, HW, C, \
-    magic40(HW), mask_out ? (const TT*)x : nullptr, (const TT*)bn_y, bn_coef, bn_acc_mode ? nullptr : bn_slab, \
-    bn_acc_mode ? (unsigned long long*)bn_slab : nullptr)
+    magic40(HW), mask_out ? (const TT*)x : nullptr, (const TT*)bn_y, bn_coef, accm ? nullptr : bn_slab, \
+    accm ? (unsigned long long*)bn_slab : nullptr)
   if (dtype) { if (bn_slab) SE_APPLY(bf16_t, true); else SE_APPLY(bf16_t, false); }
   else { if (bn_slab) SE_APPLY(float, true); else SE_APPLY(float, false); }
 #undef SE_APPLY

@@ -98,34 +98,79 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) 
 // commutes, so the total is bit-identical whatever order the workgroups arrive in (float atomics are not: the train step is
 // bit-reproducible, tests/test_gpu_reproducible.py), and the consumer kernel can read the finished sums in its prologue -- no
 // slab, no separate finalize launch between producer and consumer (60 such launches sat on the critical path of a train step).
-//   acc[k*C + c]: sum k of channel c, scaled by 2^SHIFT;   acc[K*C]: count of partials that were non-finite or outside the
-//   fixed-point range -- the consumer then turns the statistics into NaN (loud), as an fp32 sum would have become inf / NaN.
-// A partial is one workgroup's fp32 sum; |partial| < 2^(62-SHIFT) keeps v * 2^SHIFT exact and inside int64.
-//   BatchNorm statistics (sum y, sum y^2):          SHIFT 24  (|partial| < 2^38; resolution 6e-8)
-//   BatchNorm backward (sum g, sum g*xhat):         SHIFT 40  (|partial| < 2^22; resolution 9e-13: gradients are small numbers)
+//
+// A partial (one workgroup's fp32 sum v) is split EXACTLY into  v = hi/2^4 + lo,  hi = rint(16 v) an integer, |lo| <= 2^-5, and the
+// two halves go to two integer planes: hi as it is, lo scaled by 2^50.  Range and resolution are therefore independent:
+//   |v| < 2^41 (2.2e12) per partial, resolution 2^-50 (8.9e-16) -- both BatchNorm statistics (sum y, sum y^2) and the BatchNorm
+//   backward sums (sum g, sum g*xhat; under GradScaler these are multiplied by a loss scale that doubles every 2000 clean steps,
+//   training/train.py:179-195) fit with one format.
+// The TOTAL cannot wrap: with at most VQA_ACC_MAX_PARTS = 2^17 partials per sum (the launchers refuse larger grids) the hi plane
+// stays below 2^45 * 2^17 = 2^62 and the lo plane below 2^45 * 2^17 as well, replicas included.  (Round 3 range-checked only the
+// partial: ~96 partials just under the old 2^22 backward limit wrapped the int64 total silently -- finite and wrong.)
+// A partial outside the range, or NaN / inf, raises the flag word; the consumer then turns the statistics into NaN (loud: under AMP
+// the GradScaler sees non-finite gradients, skips the step and backs the scale off, as it would for an fp16 overflow).
 // ------------------------------------------------------------------------------------------------------------------
 // Replicas: a sum lives in R copies (producer workgroup w adds to copy w % R, the consumer adds the copies as integers) because
 // atomics on ONE address are serialised at ~21 ns each on MI355X (tools/atomic_bench.hip: 768 workgroups x 256 addresses 57 us with
 // one copy, 4 us with eight); R = 512 / C clamped to 1..8 keeps R*C constant, so a consumer prologue reads the same few KB whatever C.
-//   layout: acc[(r*K + k)*C + c] for replica r, sum k, channel c;  flag at acc[R*K*C];  vqa_bn_acc_words(K, C) words in all.
+//   layout (n = R*K*C):  hi plane acc[(r*K + k)*C + c] | flag acc[n] | lo plane acc[n + 1 + (r*K + k)*C + c];
+//   vqa_bn_acc_words(K, C) = 2n + 1 rounded up to even, caller-zeroed.
 static inline __host__ __device__ int acc_replicas(int C) { const int r = 512 / (C > 0 ? C : 1); return r < 1 ? 1 : (r > 8 ? 8 : r); }
-#define VQA_ACC_FWD_SHIFT 24
-#define VQA_ACC_BWD_SHIFT 40
-template <int SHIFT>
-__device__ __forceinline__ void acc_add_fixed(unsigned long long* acc, float v, unsigned long long* flag) {
-  constexpr float lim = (float)(1ull << (62 - SHIFT)), scale = (float)(1ull << SHIFT);
-  if (fabsf(v) < lim) atomicAdd(acc, (unsigned long long)__float2ll_rn(v * scale));      // (NaN fails the comparison too)
-  else atomicAdd(flag, 1ull);
+#define VQA_ACC_HI_SHIFT 4
+#define VQA_ACC_LO_SHIFT 50
+#define VQA_ACC_MAX_PARTS (1 << 17)
+#define VQA_ACC_LIMIT_LOG2 (62 - VQA_ACC_HI_SHIFT - 17)       // 41
+// idx = (r*K + k)*C + c,  n = R*K*C
+__device__ __forceinline__ void acc_add_fixed(unsigned long long* acc, size_t n, size_t idx, float v) {
+  constexpr float lim = (float)(1ull << VQA_ACC_LIMIT_LOG2), hs = (float)(1 << VQA_ACC_HI_SHIFT), lscale = (float)(1ull << VQA_ACC_LO_SHIFT);
+  if (fabsf(v) < lim) {                                                          // (NaN fails the comparison too)
+    const float hi = rintf(v * hs);                                              // integer, |hi| < 2^45: the conversion below is exact
+    const float lo = __builtin_fmaf(hi, -1.f / hs, v);                           // exact: a multiple of ulp(v) no larger than 2^-5
+    atomicAdd(acc + idx, (unsigned long long)(long long)hi);
+    if (lo != 0.f) atomicAdd(acc + n + 1 + idx, (unsigned long long)__float2ll_rn(lo * lscale));
+  } else atomicAdd(acc + n, 1ull);
 }
 // sum k of channel c over the R <= 8 replicas (integer addition: exact, order-free), as a double.  All loads are issued before
 // the first add: a serial loop over a runtime R is a chain of dependent L2 latencies (24 of them cost a consumer 12 us).
-template <int SHIFT>
 __device__ __forceinline__ double acc_read_fixed(const unsigned long long* acc, int R, int K, int C, int k, int c) {
-  long long v[8];
+  const size_t n = (size_t)R * K * C;
+  long long h[8], l[8];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = r < R ? (long long)acc[((size_t)r * K + k) * C + c] : 0ll;
-  const long long t = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-  return (double)t * (1.0 / (double)(1ull << SHIFT));
+  for (int r = 0; r < 8; ++r) {
+    const size_t i = ((size_t)r * K + k) * C + c;
+    h[r] = r < R ? (long long)acc[i] : 0ll;
+    l[r] = r < R ? (long long)acc[n + 1 + i] : 0ll;
+  }
+  const long long th = ((h[0] + h[1]) + (h[2] + h[3])) + ((h[4] + h[5]) + (h[6] + h[7]));
+  const long long tl = ((l[0] + l[1]) + (l[2] + l[3])) + ((l[4] + l[5]) + (l[6] + l[7]));
+  return (double)th * (1.0 / (double)(1 << VQA_ACC_HI_SHIFT)) + (double)tl * (1.0 / (double)(1ull << VQA_ACC_LO_SHIFT));
+}
+__device__ __forceinline__ bool acc_flagged(const unsigned long long* acc, int R, int K, int C) { return acc[(size_t)R * K * C] != 0; }
+
+struct BnAcc {
+  const unsigned long long* acc; const float* gamma; const float* beta; float* rm; float* rv; long long* nbt; float* coef;
+};
+// One evaluation per channel and workgroup (the results are shared through LDS), fp64 only for the cancellation-prone
+// var = E[y^2] - mean^2; 1/count arrives precomputed and 1/sqrt is the fp32 hardware instruction -- a first version that divided
+// and took square roots in fp64 in every thread cost 3x the streaming work of the kernel.
+__device__ __forceinline__ void bn_acc_coef(const BnAcc& f, int C, int c, double inv_count, double unbias, float momentum, float eps, bool writer,
+                                            float& sc, float& sh) {
+  const int R = acc_replicas(C);
+  const double s = acc_read_fixed(f.acc, R, 2, C, 0, c), q = acc_read_fixed(f.acc, R, 2, C, 1, c);
+  double mean = s * inv_count;
+  double var = q * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  if (acc_flagged(f.acc, R, 2, C)) mean = __builtin_nan("");                 // a partial sum left the fixed-point range / was not finite
+  const float invstd = rsqrtf((float)var + eps);
+  sc = f.gamma[c] * invstd; sh = f.beta[c] - (float)mean * sc;
+  if (writer) {
+    f.coef[c] = sc; f.coef[C + c] = sh; f.coef[2 * C + c] = (float)mean; f.coef[3 * C + c] = invstd;
+    if (f.rm) {
+      f.rm[c] = (1.f - momentum) * f.rm[c] + momentum * (float)mean;
+      f.rv[c] = (1.f - momentum) * f.rv[c] + momentum * (float)(var * unbias);
+      if (c == 0 && f.nbt) *f.nbt += 1;
+    }
+  }
 }
 
 #define VQA_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

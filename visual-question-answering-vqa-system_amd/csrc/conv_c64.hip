@@ -27,10 +27,53 @@ __device__ __forceinline__ int patch_off(int prow, int pcol, int chunk, int PWc)
 
 struct C64Params {
   const bf16_t* x; const bf16_t* w; bf16_t* out; float* stats; const bf16_t* addend; const bf16_t* addmask;
-  int stats_mode;            // 1: stats is a fixed-point accumulator u64 [2*64 + 1] (common.h acc_add_fixed), not a per-workgroup slab
+  int stats_mode;            // 1: stats is a fixed-point accumulator u64 [vqa_bn_acc_words(2, 64)] (common.h acc_add_fixed), not a per-workgroup slab
   int B, H, W; unsigned x_bytes;
   int dbg;                        // VQA_C64P_DBG (measurement only, wrong results): bit 0 no epilogue, bit 1 no MFMA loop, bit 2 no in-loop DMA
+  // 8-wave kernel only: the conv runs on relu(BatchNorm(x)) without that tensor ever existing (PreBn below)
+  int pre_mode;                   // 0: x as it is; 1: scale | shift from pre_coef[2][64]; 2: finalize pre (fixed-point statistics of x) in the prologue
+  const float* pre_coef; BnAcc pre; double pre_inv_count, pre_unbias; float pre_momentum, pre_eps;
 };
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: training-mode "Conv3x3 + BN + ReLU" (models/cnn_backbone.py:182-187) without the normalised tensor.  The 8-wave patch
+// kernels already hold their input patch in LDS for nine taps; when the input is relu(bn1(y1)) they take y1 and apply
+// scale / shift / ReLU to the patch IN LDS, once per block, right after it has landed -- a1 is never written or read (stage 1 at
+// B = 512: 205 MB each way per residual block, a whole bn_apply pass).  Same arithmetic as bn_apply_acc_kernel (fp32 fma of the
+// bf16 value, NaN-propagating ReLU, one rounding to bf16), so conv(patch) is bit-identical to conv(bn_apply(y1)).
+// Padding stays ZERO, not relu(shift): halo columns are never touched (zeroed once, DMA never writes them), rows outside the image
+// are skipped (the DMA wrote zeros there).  A thread keeps ONE channel chunk (8 channels: 16 coefficient registers, re-read from LDS
+// each block while the MFMA ring registers are dead) and walks pixels; SWZ16 selects the weight-gradient kernels' slot swizzle.
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <bool SWZ16>
+__device__ __forceinline__ void patch_bn_relu(char* patch, int nrows, int W, int PWc, int ih0, int H, const float* cf, int tid) {
+  const int c8 = tid & 7, pc0 = 1 + (tid >> 3);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = cf[c8 * 8 + j]; sh[j] = cf[64 + c8 * 8 + j]; }
+  for (int prow = 0; prow < nrows; ++prow) {
+    if ((unsigned)(ih0 + prow) >= (unsigned)H) continue;           // a padding row: stays zero
+    for (int pc = pc0; pc <= W; pc += 64) {
+      const int slot = c8 ^ (SWZ16 ? ((pc & 7) ^ (((pc >> 3) & 1) << 2)) : (pc & 7));
+      u32x4* a = reinterpret_cast<u32x4*>(patch + ((prow * PWc + pc) * 8 + slot) * 16);
+      Vec16<bf16_t> v, o; v.raw = *a;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float x = v.get(j) * sc[j] + sh[j]; o.set(j, x < 0.f ? 0.f : x); }
+      *a = o.raw;
+    }
+  }
+}
+// scale | shift of the input's BatchNorm into LDS cf[2][64] (call with >= 64 threads, then a barrier).  mode 2: finalized here from
+// the fixed-point statistics (workgroup 0 publishes coef[4][64] and updates the running statistics, like bn_apply_acc_kernel)
+__device__ __forceinline__ void pre_bn_coef(int mode, const float* pre_coef, const BnAcc& pre, double inv_count, double unbias, float momentum,
+                                            float eps, float* cf, int tid) {
+  if (tid < 64) {
+    if (mode == 2) bn_acc_coef(pre, 64, tid, inv_count, unbias, momentum, eps, blockIdx.x == 0, cf[tid], cf[64 + tid]);
+    else { cf[tid] = pre_coef[tid]; cf[64 + tid] = pre_coef[64 + tid]; }
+  }
+}
+}
 
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(C64Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -197,6 +240,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
   bf16_t* patch0 = reinterpret_cast<bf16_t*>(smem);
   bf16_t* patch1 = patch0 + patch_elems;
   float* red = reinterpret_cast<float*>(patch1 + patch_elems);  // [4 m-waves][64][2]
+  float* cf = red + 4 * 64 * 2;                                 // [2][64] scale | shift of the input's BatchNorm (pre_mode != 0)
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wm = wave >> 1;                    // wave owns channels [32*wn, 32*wn+32), m tiles wm, wm+4, ...
@@ -245,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
   const int tiles_pw = (p.dbg & 1) ? 0 : (mtiles - wm + 3) / 4;   // output stores this wave issues per block (uniform)
   int blk = blockIdx.x, buf = 0;
   if (blk < nblocks) issue_patch(blk, 0);
+  if (p.pre_mode) pre_bn_coef(p.pre_mode, p.pre_coef, p.pre, p.pre_inv_count, p.pre_unbias, p.pre_momentum, p.pre_eps, cf, tid);   // (under the first DMA)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (; blk < nblocks; blk += gridDim.x, buf ^= 1) {
@@ -252,6 +297,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
     if (nxt < nblocks && !(p.dbg & 4)) issue_patch(nxt, buf ^ 1);   // the other buffer: every wave finished reading it at the last barrier
     const unsigned pbase = lds0 + (unsigned)buf * (unsigned)(patch_elems * 2);
     const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBP;
+    if (p.pre_mode) {                                               // normalise + ReLU the landed patch in place (LDS only: no vmcnt wait)
+      patch_bn_relu<false>(smem + (size_t)buf * (size_t)(patch_elems * 2), RBP + 2, p.W, PWc, oh0 - 1, p.H, cf, tid);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     // LDS byte addresses of a tile's six (tap column, channel half) fragments in patch row 0
     auto tile_addr = [&](int mt, unsigned (&ea)[3][2], int& orow, int& ow) {
       const int px = mt * 16 + li;
@@ -336,9 +386,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
       if (p.stats_mode) {
         const int R = acc_replicas(64);
         unsigned long long* fa = reinterpret_cast<unsigned long long*>(p.stats);
-        unsigned long long* fr = fa + (size_t)(blockIdx.x % R) * 128;
-        acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + tid, s, fa + (size_t)R * 128);
-        acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + 64 + tid, q, fa + (size_t)R * 128);
+        const size_t fr = (size_t)(blockIdx.x % R) * 128;
+        acc_add_fixed(fa, (size_t)R * 128, fr + tid, s);
+        acc_add_fixed(fa, (size_t)R * 128, fr + 64 + tid, q);
       } else {
         p.stats[((size_t)blockIdx.x * 2) * 64 + tid] = s;
         p.stats[((size_t)blockIdx.x * 2 + 1) * 64 + tid] = q;
@@ -350,7 +400,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
 // ------------------------------------------------------------------------------------------------
 // weight gradient: dw[n][(r,s,c)] += sum_px dy[px][n] * x[px + (r-1, s-1)][c]
 // ------------------------------------------------------------------------------------------------
-struct C64WgradParams { const bf16_t* x; const bf16_t* dy; float* dw; float* ws; int B, H, W; unsigned x_bytes, dy_bytes; int dbg; /* VQA_C64WP_DBG, measurement only: bit 1 no MFMA loop, bit 2 no in-loop DMA */ };
+struct C64WgradParams { const bf16_t* x; const bf16_t* dy; float* dw; float* ws; int B, H, W; unsigned x_bytes, dy_bytes; int dbg; /* VQA_C64WP_DBG, measurement only: bit 1 no MFMA loop, bit 2 no in-loop DMA */
+                        const float* pre_coef; /* 8-wave kernel: x stands for relu(x * pre_coef[c] + pre_coef[64 + c]) (PreBn above), or NULL */ };
 
 __global__ __launch_bounds__(256) void wgrad3x3_c64_kernel(C64WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -563,13 +614,21 @@ __device__ __forceinline__ void wgrad_c64p_body(const C64WgradParams& p, char* s
     }
   }
 
+  float* cf = reinterpret_cast<float*>(smem + 2 * buf_bytes);   // [2][64] scale | shift of x's BatchNorm (pre_coef != NULL)
   int blk = blockIdx.x, buf = 0;
   if (blk < nblocks) issue(blk, 0);
+  if (p.pre_coef) pre_bn_coef(1, p.pre_coef, BnAcc{}, 0.0, 0.0, 0.f, 0.f, cf, tid);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (; blk < nblocks; blk += gridDim.x, buf ^= 1) {
     const int nxt = blk + gridDim.x;
     if (nxt < nblocks && !(p.dbg & 4)) issue(nxt, buf ^ 1);     // the other buffer: every wave finished reading it at the last barrier
+    if (p.pre_coef) {                                           // normalise + ReLU the landed x patch in place (both wave groups take part)
+      const int bq = blk / rblocks;
+      patch_bn_relu<true>(smem + buf * buf_bytes, RBW + 2, Wd, PWc, (blk - bq * rblocks) * RBW - 1, p.H, cf, tid);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     if constexpr (WC != 0) {
       if (p.dbg & 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); continue; }
       // Hand-issued transposed reads, counted lgkmcnt waits (LDS returns in order).  35 steps = 7 k-steps x 5 taps; at the top of
@@ -894,7 +953,7 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
   if (!x || !w || !out || grid <= 0) return VQA_EARG;
   C64Params p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
-  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.B = B; p.H = H; p.W = W; p.dbg = 0; p.stats_mode = 0;
+  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.B = B; p.H = H; p.W = W; p.dbg = 0; p.stats_mode = 0; p.pre_mode = 0; p.pre_coef = nullptr;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb;
@@ -919,10 +978,9 @@ int vqa_conv3x3_c64p_blocks(int B, int H, int W) {
   return nb < 256 ? nb : 256;
 }
 // forward / addend-free data gradient of the 64 -> 64 channel 3x3 conv with the 8-wave LDS-DMA patch kernel (no epilogue inputs)
-int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, int stats_mode, hipStream_t st) {
+static int c64p_launch(C64Params& p, const void* x, const void* w, void* out, float* stats, int B, int H, int W, int stats_mode, hipStream_t st) {
   const int grid = vqa_conv3x3_c64p_blocks(B, H, W);
   if (!x || !w || !out || grid <= 0) return VQA_EARG;
-  C64Params p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats; p.addend = nullptr; p.addmask = nullptr;
   p.B = B; p.H = H; p.W = W; p.stats_mode = stats_mode;
   const int dbg_env = vqa_env_int("VQA_C64P_DBG", 0);
@@ -931,7 +989,7 @@ int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int 
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb;
   const int rbp = c64p_rows(H, W);
-  const size_t shm = (size_t)2 * (rbp + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4;
+  const size_t shm = (size_t)2 * (rbp + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4 + 2 * 64 * 4;
   static size_t attr8 = 0, attr4 = 0;
   if (rbp == 8) {
     if (shm > attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64p_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr8 = shm; }
@@ -941,6 +999,26 @@ int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int 
     hipLaunchKernelGGL(conv3x3_c64p_kernel<4>, dim3(grid), dim3(512), shm, st, p);
   }
   VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, int stats_mode, hipStream_t st) {
+  C64Params p;
+  p.pre_mode = 0; p.pre_coef = nullptr;
+  return c64p_launch(p, x, w, out, stats, B, H, W, stats_mode, st);
+}
+// The same conv applied to relu(BatchNorm(y)) in TRAINING mode, the normalised tensor never materialised (models/cnn_backbone.py:182-187
+// conv1 -> bn1 -> relu -> conv2): y is conv1's raw output, acc its fixed-point statistics (vqa_bn_acc_words(2, 64), filled by the launch
+// that produced y with stats_mode = 1).  Every workgroup finalizes the 64 coefficients in its prologue (under its first patch DMA),
+// workgroup 0 publishes coef_out[4][64] (scale | shift | mean | invstd: the backward and vqa_wgrad3x3_c64_bn read it) and updates the
+// running statistics -- exactly what vqa_bn_apply_acc does, minus its read of y and write of a.  The patch is transformed in LDS.
+int vqa_conv3x3_c64p_bn(const void* y, const unsigned long long* acc, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, long long* num_batches_tracked, float* coef_out, const void* w, void* out, float* stats,
+                        int B, int H, int W, int stats_mode, double count, float momentum, float eps, hipStream_t st) {
+  if (!acc || !gamma || !beta || !coef_out || count <= 0) return VQA_EARG;
+  C64Params p;
+  p.pre_mode = 2; p.pre_coef = nullptr;
+  p.pre = BnAcc{acc, gamma, beta, running_mean, running_var, num_batches_tracked, coef_out};
+  p.pre_inv_count = 1.0 / count; p.pre_unbias = count > 1 ? count / (count - 1) : 1.0; p.pre_momentum = momentum; p.pre_eps = eps;
+  return c64p_launch(p, y, w, out, stats, B, H, W, stats_mode, st);
 }
 // dw [64][576] fp32 (+=).  ws: scratch of >= vqa_conv3x3_c64_blocks(B,H,W) * 64*576 floats for the deterministic two-pass
 // accumulation (NULL or too small: fp32 atomics)
@@ -984,14 +1062,15 @@ int vqa_wgrad3x3_c64_blocks(int B, int H, int W) {
   const int nblk = rbw ? B * (H / rbw) : 0, gp = nblk < 256 ? nblk : 256;
   return g4 > gp ? g4 : gp;
 }
-int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t st) {
+static int c64_wgrad_launch(const void* x, const float* pre_coef, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats,
+                            hipStream_t st) {
   const int grid = vqa_conv3x3_c64_blocks(B, H, W);            // the 4-wave kernel's persistent grid (0: it does not take the shape)
   size_t shm_p = 0;
   const int rbw = c64wp_rows(H, W, &shm_p);
   const int nblk_p = rbw ? B * (H / rbw) : 0, grid_p = nblk_p < 256 ? nblk_p : 256;
   if (!x || !dy || !dw || (grid <= 0 && grid_p <= 0)) return VQA_EARG;
   C64WgradParams p;
-  p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.B = B; p.H = H; p.W = W;
+  p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.dw = dw; p.B = B; p.H = H; p.W = W; p.pre_coef = pre_coef;
   const int dbg_env = vqa_env_int("VQA_C64WP_DBG", 0);
   p.dbg = dbg_env;
   const size_t xb = (size_t)B * H * W * CH * 2;
@@ -1001,6 +1080,7 @@ int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int
   const int wp_env = vqa_env_int("VQA_C64WP", 1);
   if (wp_env && ws && grid_p > 0 && ws_floats >= (long long)grid_p * 64 * 576) {
     p.ws = ws;
+    shm_p += 2 * 64 * 4;                                        // cf[2][64] behind the two buffers
     static size_t attr4 = 0, attr2 = 0;
     if (rbw == 4) {
       if (shm_p > attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_c64p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_p); attr4 = shm_p; }
@@ -1012,7 +1092,7 @@ int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int
     VQA_LAUNCH_CHECK();
     return vqa_slab_reduce(p.ws, dw, grid_p, 64 * 576, st);
   }
-  if (grid <= 0) return VQA_EARG;
+  if (grid <= 0 || pre_coef) return VQA_EARG;                   // (the 4-wave kernel has no BatchNorm prologue)
   p.ws = (ws && ws_floats >= (long long)grid * 64 * 576) ? ws : nullptr;
   const int MP = (RBG * W + 31) / 32 * 32;
   const size_t shm = (size_t)(RBG + 2) * (W + 2) * CH * 2 + (size_t)MP * (CH + 4) * 2;
@@ -1021,6 +1101,19 @@ int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int
   hipLaunchKernelGGL(wgrad3x3_c64_kernel, dim3(grid), dim3(256), shm, st, p);
   VQA_LAUNCH_CHECK();
   return p.ws ? vqa_slab_reduce(p.ws, dw, grid, 64 * 576, st) : VQA_OK;
+}
+int vqa_wgrad3x3_c64_bn_ok(int B, int H, int W) {               // 1: vqa_wgrad3x3_c64_bn takes this shape (the 8-wave kernel does)
+  return B > 0 && H > 0 && c64wp_rows(H, W, nullptr) > 0 && vqa_env_int("VQA_C64WP", 1) && (size_t)B * H * W * CH * 2 < 0x7fffffffull;
+}
+int vqa_wgrad3x3_c64(const void* x, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats, hipStream_t st) {
+  return c64_wgrad_launch(x, nullptr, dy, dw, B, H, W, ws, ws_floats, st);
+}
+// dw += dy^T * gather(relu(y * coef[c] + coef[64 + c])): the weight gradient of the conv that vqa_conv3x3_c64p_bn ran on the
+// un-materialised activation; coef = the [4][64] table that launch published.  8-wave kernel only (needs the slab workspace).
+int vqa_wgrad3x3_c64_bn(const void* y, const float* coef, const void* dy, float* dw, int B, int H, int W, float* ws, long long ws_floats,
+                        hipStream_t st) {
+  if (!coef) return VQA_EARG;
+  return c64_wgrad_launch(y, coef, dy, dw, B, H, W, ws, ws_floats, st);
 }
 
 }  // extern "C"

@@ -20,7 +20,7 @@ struct IGemmParams {
   const void* a; const void* w; void* out;
   const float* bias; const void* addend; const void* addmask; float* stats;
   const void* outmask;       // != nullptr: out = (... + addend) * (outmask > 0): the consumer's ReLU mask applied by the producer
-  int stats_mode;            // 0: stats is a float slab [tiles][2][N]; 1: a fixed-point accumulator u64 [2*N + 1] (common.h acc_add_fixed)
+  int stats_mode;            // 0: stats is a float slab [tiles][2][N]; 1: a fixed-point accumulator u64 [vqa_bn_acc_words(2, N)] (common.h acc_add_fixed)
   int M, N, Kp, Kw;          // Kp: reduction length rounded up to BK; Kw: weight row length (elements)
   int B, H, W, C;            // source tensor (NHWC; NCHW fp32 image for the stem loader)
   int Ho, Wo;                // spatial dims of the GEMM rows (M = B*Ho*Wo)
@@ -574,9 +574,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
           if (p.stats_mode) {                                  // order-free fixed-point sums: the consumer finalizes them itself
             const int R = acc_replicas(p.N);
             unsigned long long* fa = reinterpret_cast<unsigned long long*>(p.stats);
-            unsigned long long* fr = fa + (size_t)(tile_m % R) * 2 * p.N;
-            if (sg == 0) acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + n, dsum[0], fa + (size_t)R * 2 * p.N);
-            if (sg == sq) acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + p.N + n, qv, fa + (size_t)R * 2 * p.N);
+            const size_t fr = (size_t)(tile_m % R) * 2 * p.N;
+            if (sg == 0) acc_add_fixed(fa, (size_t)R * 2 * p.N, fr + n, dsum[0]);
+            if (sg == sq) acc_add_fixed(fa, (size_t)R * 2 * p.N, fr + p.N + n, qv);
           } else {
             if (sg == 0) p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = dsum[0];
             if (sg == sq) p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = qv;
@@ -593,9 +593,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
       if (p.stats_mode) {
         const int R = acc_replicas(p.N);
         unsigned long long* fa = reinterpret_cast<unsigned long long*>(p.stats);
-        unsigned long long* fr = fa + (size_t)(tile_m % R) * 2 * p.N;
-        acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + n, s, fa + (size_t)R * 2 * p.N);
-        acc_add_fixed<VQA_ACC_FWD_SHIFT>(fr + p.N + n, q, fa + (size_t)R * 2 * p.N);
+        const size_t fr = (size_t)(tile_m % R) * 2 * p.N;
+        acc_add_fixed(fa, (size_t)R * 2 * p.N, fr + n, s);
+        acc_add_fixed(fa, (size_t)R * 2 * p.N, fr + p.N + n, q);
       } else {
         p.stats[((size_t)tile_m * 2 + 0) * p.N + n] = s;
         p.stats[((size_t)tile_m * 2 + 1) * p.N + n] = q;
@@ -1541,6 +1541,7 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
   }
   if ((long)M != (long)B * Ho * Wo) return VQA_EARG;
   if (drop_p > 0.f && (unsigned long long)M * (unsigned long long)N >= (1ull << 32)) return VQA_EARG;   // 32-bit dropout counter
+  if (stats && stats_mode && (M + 63) / 64 > VQA_ACC_MAX_PARTS) return VQA_EARG;   // one partial per M tile: the fixed-point total must not wrap (common.h)
   IGemmParams p;
   p.a = a; p.w = w; p.out = out; p.bias = bias; p.addend = addend; p.addmask = addmask; p.stats = stats; p.outmask = outmask;
   p.stats_mode = stats_mode;

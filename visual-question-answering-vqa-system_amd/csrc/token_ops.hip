@@ -713,15 +713,21 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(float* out, int nparts
 }
 // clip_grad_norm_(max_norm) + AdamW (decoupled weight decay), torch semantics (training/train.py:204-208,127-132)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
-                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, const float* __restrict__ sumsq,
+                             float lr, float b1, float b2, float eps, float wd, long long calls, const float* __restrict__ sumsq,
                              float max_norm, float gscale, const int* __restrict__ skip, int* __restrict__ skipped) {
   // skip[0] != 0 (rows with an out-of-range target in THIS step, summed over ranks): the reference raises before
   // optimizer.step() (nn.CrossEntropyLoss, training/train.py:120,182-208) and leaves the model intact -- so does this kernel:
-  // parameters and both moments stay untouched; skipped[0] += rows, skipped[1] += 1 (read by the host at its logging interval).
+  // parameters and both moments stay untouched; skipped[0] += rows, skipped[1] += 1 (read by the host at its logging interval),
+  // skipped[2] += 1 (never reset: the device-side record of how many launches did NOT count as an optimizer step).
   if (skip && *skip != 0) {
-    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) { skipped[0] += *skip; skipped[1] += 1; }
+    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) { skipped[0] += *skip; skipped[1] += 1; skipped[2] += 1; }
     return;
   }
+  // Adam's step number lives on the DEVICE: calls (the host's launch count, this one included) minus the launches skipped so far.
+  // skipped[2] is only written by a launch that skips, and such a launch reads it nowhere else: no race.  (Round 3 derived the bias
+  // corrections from a host counter that was repaired only at the caller's next check(): every step in between ran one step ahead.)
+  const long long t = calls - (skipped ? (long long)skipped[2] : 0ll);
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)t)), bc2 = (float)(1.0 - pow((double)b2, (double)t));
   float coef = gscale;
   if (sumsq && max_norm > 0.f) {
     const float norm = sqrtf(*sumsq) * gscale;
@@ -984,9 +990,10 @@ int vqa_sumsq(const float* g, long long n, float* out, hipStream_t st) {
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
-              float bc1, float bc2, const float* sumsq, float max_norm, float gscale, const int* skip, int* skipped, hipStream_t st) {
+              long long calls, const float* sumsq, float max_norm, float gscale, const int* skip, int* skipped, hipStream_t st) {
+  if (calls < 1) return VQA_EARG;
   size_t blocks = ((size_t)n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, bc1, bc2, sumsq, max_norm, gscale,
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, calls, sumsq, max_norm, gscale,
                      skip, skipped);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }

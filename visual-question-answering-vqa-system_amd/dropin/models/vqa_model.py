@@ -173,6 +173,13 @@ class VQAModel(nn.Module):
         # the 164 Parameter objects never change identity (.to() only swaps their .data), but resolving 164 dotted names through
         # nn.Module.__getattr__ on every forward cost the unchanged train.py loop a few hundred host microseconds with the GPU idle
         pl = self.__dict__.get("_params_cache")
+        if pl is not None:
+            # nn.Module._apply may REPLACE Parameter objects (torch.__future__.set_overwrite_module_params_on_conversion) and a user
+            # may re-register one: a stale list would route gradients to orphans (optimizer sees grad = None).  _reflatten drops the
+            # cache; this two-lookup probe (first and last parameter) catches the re-registration case
+            e0, e1 = self._param_entries[0], self._param_entries[-1]
+            if getattr_path(self, e0.name) is not pl[0] or getattr_path(self, e1.name) is not pl[-1]:
+                pl = None
         if pl is None:
             pl = [getattr_path(self, e.name) for e in self._param_entries]
             self.__dict__["_params_cache"] = pl
@@ -196,6 +203,10 @@ class VQAModel(nn.Module):
                 p.grad = None
         self._flat = flat
         self._engine = None
+        self.__dict__.pop("_params_cache", None)
+        if self._graphs:                             # captured graphs hold the OLD flat buffer's pointers
+            torch.cuda.synchronize()
+            self._graphs.clear()
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -250,7 +261,8 @@ class VQAModel(nn.Module):
             raise RuntimeError("forward_graphed is the inference path: call model.eval() first")
         if not images.is_cuda:
             raise RuntimeError("VQAModel (HIP) got CPU inputs; this implementation only runs on an MI355X (no CPU fallback)")
-        key = (tuple(images.shape), tuple(token_ids.shape), attention_mask is not None, self._flat.data_ptr(), self._ensure_engine().fold_eval)
+        key = (tuple(images.shape), tuple(token_ids.shape), attention_mask is not None, self._flat.data_ptr(), self._ensure_engine().fold_eval,
+               getattr(self._engine, "fuse_stem_eval", None))
         g = self._graphs.pop(key, None)
         if g is not None:
             self._graphs[key] = g                    # LRU: a hit moves the shape to the young end

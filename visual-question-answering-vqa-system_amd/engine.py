@@ -98,6 +98,9 @@ class HipEngine:
         # integer accumulators (order-free atomics), so conv -> [finalize] -> apply and reduce -> [finalize] -> apply lose their
         # middle launches (60 per step on the critical path; upper bound measured with tools/ab_nofinalize.py: -0.5 ms of 12.9)
         self.fuse_bn_finalize = True
+        # round 4: stage-1 conv1 -> bn1 -> relu -> conv2 without the normalised tensor a1: conv2 (8-wave patch kernel) and its weight
+        # gradient take conv1's raw output and apply scale / shift / ReLU to their LDS patch (one bn_apply pass less per block)
+        self.fuse_bn_conv = True
         self._accbuf = None
         self._accpos = 0
         self._stem_fcoef = None
@@ -559,12 +562,21 @@ class HipEngine:
                 facc = training and self.fuse_bn_finalize and T == torch.bfloat16
                 y1, st1, mt1, g1, Ho, Wo = self._conv(x, B, H, W, Cin, p + ".conv1.weight", Cout, 3, stride, 1, training, acc=facc)
                 M = B * Ho * Wo
-                if mt1 < 0:                                  # statistics in a fixed-point accumulator: finalize + apply in one launch
+                fuse12 = (mt1 < 0 and self.fuse_bn_conv and need_tape and self._c64p_ok(B, Ho, Wo, Cout, Cout, 3, 1)
+                          and K.c64w_bn_ok(B, Ho, Wo))
+                if fuse12:                                   # conv2 normalises conv1's raw output in its LDS patch: a1 never exists
+                    a1 = None
+                    a2 = self._acc(K.L.count("vqa_bn_acc_words", 2, Cout))
+                    y2, st2, _, c1 = K.conv3x3_c64p_bn(y1, st1, self._bn_params(p + ".bn1"), self.Wm(p + ".conv2.weight"), B, Ho, Wo, M,
+                                                       want_stats=True, stats_acc=a2)
+                    mt2, g2 = -1, (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
+                elif mt1 < 0:                                # statistics in a fixed-point accumulator: finalize + apply in one launch
                     a1, c1, _, _, _ = K.bn_apply_acc(y1, st1, self._bn_params(p + ".bn1"), Cout, True, B, Ho * Wo, M)
                 else:
                     c1 = self._bn_coef(p + ".bn1", st1, mt1, Cout, M, training)
                     a1 = K.bn_apply(y1, c1, Cout, relu=True)
-                y2, st2, mt2, g2, _, _ = self._conv(a1, B, Ho, Wo, Cout, p + ".conv2.weight", Cout, 3, 1, 1, training, acc=facc)
+                if not fuse12:
+                    y2, st2, mt2, g2, _, _ = self._conv(a1, B, Ho, Wo, Cout, p + ".conv2.weight", Cout, 3, 1, 1, training, acc=facc)
                 c2 = None if mt2 < 0 else self._bn_coef(p + ".bn2", st2, mt2, Cout, M, training)
                 rec = dict(p=p, x=x, y1=y1, c1=c1, a1=a1, y2=y2, c2=c2, g1=g1, g2=g2, M=M, Cin=Cin, Cout=Cout)
                 # the stage's last block hands the SE pooling sums over (its output is the SE input)
@@ -891,7 +903,7 @@ class HipEngine:
                 dxc = dxn
             if "se" in srec:
                 r = srec["se"]
-                scratch = torch.empty((B * (2 * r["C"] + r["Cr"]),), device=dxc.device, dtype=torch.float32)
+                scratch = torch.empty((K.L.count("vqa_se_bwd_scratch", dt(T), B, r["HW"], r["C"], r["Cr"]),), device=dxc.device, dtype=torch.float32)
                 dxn = torch.empty_like(r["x"])
                 # dxn is the gradient entering the last block's bn2: its BatchNorm-backward column sums leave the same pass
                 lastb = srec["blocks"][-1]
@@ -1013,7 +1025,9 @@ class HipEngine:
                             facc=(pre[0] if pre_acc else (self._acc(K.L.count("vqa_bn_acc_words", 3, Cout)) if bacc else None)), facc_filled=pre_acc)
         g2 = rec["g2"]; B, Ho, Wo = g2[0], g2[1], g2[2]
         c64_2 = self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1)
-        if self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1, wgrad=True):
+        if rec["a1"] is None:                                 # conv2 ran on relu(bn1(y1)) built in LDS (fuse_bn_conv): so does its weight gradient
+            self._off_path([dy2], lambda: K.wgrad3x3_c64_bn(rec["y1"], rec["c1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo), defer=last)
+        elif self._c64_ok(B, Ho, Wo, Cout, Cout, 3, 1, wgrad=True):
             self._off_path([dy2], lambda: K.wgrad3x3_c64(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo), defer=last)
         elif self._c128w_ok(B, Ho, Wo, Cout, Cout, 1):
             self._off_path([dy2], lambda: K.wgrad3x3_c128(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo))

@@ -163,6 +163,42 @@ def conv3x3_c64p(x, w, B, H, W, *, want_stats=False, stats_acc=None):
     return out, stats, nb
 
 
+def conv3x3_c64p_bn(y, acc, bn, w, B, H, W, count, *, want_stats=False, stats_acc=None, momentum=0.1, eps=1e-5):
+    """conv3x3_c64p(relu(BatchNorm_train(y))) without the normalised tensor: y = the previous conv's raw output, acc = its fixed-point
+    statistics, bn = (gamma, beta, running_mean, running_var, num_batches_tracked).  Returns (out, stats | None, blocks, coef [4][64])."""
+    nb = c64p_blocks(B, H, W)
+    out = torch.empty((B * H * W, 64), device=y.device, dtype=torch.bfloat16)
+    coef = torch.empty((4, 64), device=y.device, dtype=torch.float32)
+    stats = torch.empty((nb, 2, 64), device=y.device, dtype=torch.float32) if (want_stats and stats_acc is None) else stats_acc
+    g, b_, rm, rv, nbt = bn
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_conv3x3_c64p_bn", ptr(y), ptr(acc), ptr(g), ptr(b_), ptr(rm), ptr(rv), ptr(nbt), ptr(coef), ptr(w), ptr(out), ptr(stats), B, H, W,
+         int(stats_acc is not None), float(count), momentum, eps)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("conv3x3_c64p_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
+    return out, stats, nb, coef
+
+
+def c64w_bn_ok(B, H, W) -> bool:
+    return L.count("vqa_wgrad3x3_c64_bn_ok", B, H, W) > 0
+
+
+def wgrad3x3_c64_bn(y, coef, dy, dw, B, H, W):
+    """dw += dy^T gather(relu(y * coef[0] + coef[1])): weight gradient of the conv that conv3x3_c64p_bn ran (8-wave kernel)."""
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    wsf = c64w_blocks(B, H, W) * 64 * 576
+    ws = torch.empty(wsf, device=y.device, dtype=torch.float32)
+    call("vqa_wgrad3x3_c64_bn", ptr(y), ptr(coef), ptr(dy), ptr(dw), B, H, W, ptr(ws), wsf)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("wgrad3x3_c64", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
+
+
 def c64w_blocks(B, H, W) -> int:
     """Slabs vqa_wgrad3x3_c64 wants (8-wave LDS-DMA kernel: 4 or 2 rows per block; else the 4-wave kernel); 0: unsupported shape."""
     return L.count("vqa_wgrad3x3_c64_blocks", B, H, W)

@@ -155,8 +155,11 @@ class HipTrainer:
         self._scal = torch.zeros(2, device=flat.device, dtype=torch.int32)
         self.loss = self._scal[0:1].view(torch.float32)
         self.bad_step = self._scal[1:2]
-        self.bad_targets = torch.zeros(2, device=flat.device, dtype=torch.int32)   # {rows out of range, steps skipped} since the last check()
-        self.t = 0
+        # {rows out of range, steps skipped} since the last check(), and [2]: steps skipped EVER (the AdamW kernel forms Adam's
+        # step number as calls - skipped-ever on the device: a skipped step never advances the bias corrections, check() or not)
+        self._bad = torch.zeros(3, device=flat.device, dtype=torch.int32)
+        self.bad_targets = self._bad[:2]
+        self.calls = 0
         self.buckets = LY.bucket_ranges(model._entries)
         self.reducer = GradBucketReducer(self.G, self.buckets, process_group, overlap, force=force_reducer,
                                          avoid_streams=[st for st in (self.engine.side, self.engine.side2) if st is not None])
@@ -195,12 +198,16 @@ class HipTrainer:
         eng.backward(tape, dlogits, self.G, on_segment=self.reducer.on_segment if self.reducer.active else None)
         gscale = self.reducer.finish()
         call("vqa_sumsq", ptr(self.G), self.G.numel(), ptr(self.sumsq))
-        self.t += 1
+        self.calls += 1
         b1, b2 = self.betas
         call("vqa_adamw", ptr(self.model._flat), ptr(self.G), ptr(self.m), ptr(self.v), self.G.numel(), self.lr, b1, b2, self.eps,
-             self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, ptr(self.sumsq), float(self.max_norm), gscale,
-             ptr(self.bad_step), ptr(self.bad_targets))
+             self.wd, self.calls, ptr(self.sumsq), float(self.max_norm), gscale, ptr(self.bad_step), ptr(self._bad))
         return self.loss, logits_f
+
+    @property
+    def t(self) -> int:
+        """Adam's step number = optimizer updates actually applied (one host sync; the kernels never need it from the host)."""
+        return self.calls - int(self._bad[2])
 
     def grad_norm(self) -> torch.Tensor:
         return self.sumsq[:1].sqrt() / self.world
@@ -211,6 +218,5 @@ class HipTrainer:
         n, skipped = (int(x) for x in self.bad_targets.tolist())
         if n:
             self.bad_targets.zero_()
-            self.t -= skipped                     # the skipped updates never happened: keep Adam's bias correction in step
             raise IndexError(f"{n} target(s) out of range [0, {self.model.num_answers}) since the last check: {skipped} step(s) were "
                              "skipped on every rank (parameters and optimizer state untouched; that step's loss and gradients are NaN)")
