@@ -64,6 +64,18 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
 int vqa_conv3x3_c64p_blocks(int B, int H, int W);
 int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W,
                      int stats_mode /* 1: stats is the fixed-point accumulator u64 [2*64 + 1] of vqa_bn_apply_acc */, hipStream_t stream);
+/* Round 4 -- the 256 x 256 x 64 8-phase GEMM core (csrc/gemm8p.hip): C[M][N] = A[M][K] . B[N][K]^T, bf16 operands, fp32 accumulation,
+ * bf16 result; M % 256 == 0, N % 256 == 0, K % 64 == 0.  The dense form of the tile that vqa_conv8p runs as an implicit GEMM. */
+int vqa_gemm8p(const void* A, const void* B, void* C, int M, int N, int K, hipStream_t stream);
+/* vqa_conv8p: the same tile as an implicit-GEMM 3x3 / stride 1 / pad 1 convolution over NHWC bf16 (models/cnn_backbone.py:182-187 at
+ * 256 / 512 channels): out[B*H*W][N] = conv(x [B][H][W][C], w [N][(r, s, c)]) with transposed = 0; with transposed = 1 the stride-1 data
+ * gradient (x = dy [B][H][W][Cout], w = the [Cin][(tap, Cout)] pack of vqa_pack_transpose, taps mirrored).  Tiles hold 196 valid output
+ * pixels of 224 when 196 divides B*H*W (one 14 x 14 image / four 7 x 7 images: exactly 2 / 1 rounds of 256 CUs at B = 512).
+ * stats: NULL, or the fixed-point BatchNorm accumulator (vqa_bn_acc_words(2, N), caller-zeroed) for sum y | sum y^2 of the stored values.
+ * vqa_conv8p_ok: 1 when the shape is taken (C a power-of-two multiple of 64, N a multiple of 256). */
+int vqa_conv8p_ok(int B, int H, int W, int C, int N);
+int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stats, int B, int H, int W, int C, int N, int transposed,
+               hipStream_t stream);
 /* Round 4 -- training-mode "Conv3x3 + BN + ReLU" without the normalised tensor (models/cnn_backbone.py:182-187: conv1 -> bn1 -> relu ->
  * conv2 at 64 channels).  vqa_conv3x3_c64p_bn is vqa_conv3x3_c64p applied to relu(BatchNorm(y)): y = the previous conv's raw output,
  * acc = its fixed-point statistics (the launch that wrote y ran with stats_mode = 1).  Every workgroup finalizes the 64 coefficients in

@@ -1,0 +1,77 @@
+"""The 8-phase GEMM core (csrc/gemm8p.hip): dense GEMM against fp32 matmul, and the implicit-GEMM 3x3 conv / data gradient against
+ATen convolutions on the same bf16 operands and BIT-comparable against the 128x128 igemm tile's fp32 accumulation order is NOT
+expected (different K order inside a tile) -- the bound is the bf16 rounding of the stored value."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _pkg import sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+bf = torch.bfloat16
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 256, 128), (256, 512, 192), (1024, 768, 2304), (768, 256, 4608)])
+def test_gemm8p_matches_matmul(M, N, K):
+    L = sub("_lib")
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(DEV, bf)
+    B = torch.randn(N, K, generator=g).to(DEV, bf)
+    C = torch.full((M, N), float("nan"), device=DEV, dtype=bf)
+    L.call("vqa_gemm8p", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K)
+    torch.cuda.synchronize()
+    ref = A.float() @ B.float().t()
+    assert torch.isfinite(C.float()).all()
+    assert (C.float() - ref).abs().max().item() <= 6e-3 * ref.abs().max().item()
+    with pytest.raises(RuntimeError):
+        L.call("vqa_gemm8p", A.data_ptr(), B.data_ptr(), C.data_ptr(), M + 1, N, K)
+
+
+def _acc_decode(acc, R, K, C):
+    n = R * K * C
+    return (acc[:n].view(R, K, C).sum(0).double() / 16.0 + acc[n + 1: 2 * n + 1].view(R, K, C).sum(0).double() / float(1 << 50)), int(acc[n])
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(4, 14, 14, 256, 256), (8, 7, 7, 512, 512), (3, 14, 14, 256, 256), (5, 7, 7, 512, 512), (2, 28, 28, 128, 256),
+                                       (1, 5, 9, 64, 256), (16, 14, 14, 256, 256)])
+@pytest.mark.parametrize("transposed", [0, 1])
+def test_conv8p_matches_aten(B, H, W, C, N, transposed):
+    """Forward: conv2d(x, w, padding=1).  transposed: the stride-1 data gradient dx = conv_transpose2d(dy, w) through the packed
+    [Cin][(tap, Cout)] operand (vqa_pack_transpose), exactly how engine._block_bwd calls the igemm kernel."""
+    K, L = sub("kernels"), sub("_lib")
+    assert K.conv8p_ok(B, H, W, C, N)
+    g = torch.Generator().manual_seed(B * 100 + H + C + N + transposed)
+    x = torch.randn(B * H * W, C, generator=g).to(DEV, bf)
+    if not transposed:
+        w = (torch.randn(N, 3, 3, C, generator=g) * 0.05)                       # [Cout][R][S][Cin]
+        wq = w.to(DEV, bf)
+        acc = torch.zeros(L.count("vqa_bn_acc_words", 2, N), device=DEV, dtype=torch.int64)
+        out = K.conv8p(x, wq.view(N, 9 * C), B, H, W, C, N, stats_acc=acc)
+        ref = F.conv2d(x.float().view(B, H, W, C).permute(0, 3, 1, 2).cpu(), wq.float().permute(0, 3, 1, 2).cpu(), padding=1)
+    else:
+        # data gradient of a conv with weight w [Cout = C][3][3][Cin = N]: dx[b,h,w,n] = sum dy[b,h+1-r,w+1-s,c] w[c][r][s][n]
+        w = torch.randn(C, 3, 3, N, generator=g) * 0.05
+        wq = w.to(bf).float()
+        wt = K.pack_transpose(wq.view(C, 9, N).to(DEV), bf)                      # [N][(tap, C)]
+        out = K.conv8p(x, wt.view(N, 9 * C), B, H, W, C, N, transposed=1)
+        ref = F.conv_transpose2d(x.float().view(B, H, W, C).permute(0, 3, 1, 2).cpu(), wq.permute(0, 3, 1, 2), padding=1)
+    torch.cuda.synchronize()
+    got = out.float().view(B, H, W, N).permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 6e-3 * max(1.0, ref.abs().max().item())
+    # the igemm tile on the same operands: same bf16 result up to one rounding of sums taken in a different order
+    geom = (B, H, W, C, H, W, 3, 3, 1, 1)
+    o2, _, _ = K.igemm(x, (wq.to(DEV).view(N, 9 * C) if not transposed else wt.view(N, 9 * C)), B * H * W, N, 9 * C, geom, dtype=bf, transposed=transposed)
+    assert (out.float() - o2.float()).abs().max().item() <= 1.6e-2 * max(1.0, float(o2.float().abs().max()))
+    if not transposed:
+        R = max(1, min(8, 512 // N))
+        sums, flag = _acc_decode(acc, R, 2, N)
+        of = out.double()
+        assert flag == 0
+        assert (sums[0] - of.sum(0)).abs().max().item() <= 1e-3 * max(1.0, float(of.sum(0).abs().max()))
+        assert (sums[1] - (of * of).sum(0)).abs().max().item() <= 1e-3 * float((of * of).sum(0).max())
+        # bit-reproducible
+        acc2 = torch.zeros_like(acc)
+        out2 = K.conv8p(x, wq.view(N, 9 * C), B, H, W, C, N, stats_acc=acc2)
+        assert torch.equal(out, out2) and torch.equal(acc, acc2)

@@ -17,6 +17,9 @@ P, I, F, D, LL, ULL = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong, 
 
 # name -> argument ctypes (all return int; last argument is always the stream unless noted)
 SIGNATURES = {
+    "vqa_gemm8p": [P, P, P, I, I, I, P],
+    "vqa_conv8p_ok": [I, I, I, I, I],
+    "vqa_conv8p": [P, P, P, P, I, I, I, I, I, I, P],
     "vqa_igemm_mtiles": [I, I, I],
     "vqa_igemm_variant": [I] * 15,
     "vqa_igemm": [I, I, P, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, I, P],
@@ -104,7 +107,7 @@ SIGNATURES = {
     "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, LL, P, F, F, P, P, P],
 }
 _RET_LL = {"vqa_image_resize_ws", "vqa_wgrad_group_ws", "vqa_spatial_bwd_scratch", "vqa_se_bwd_scratch", "vqa_layernorm_bwd_ws", "vqa_bias_act_bwd_ws"}                       # return a size (long long)
-_NO_STATUS = _RET_LL | {"vqa_wgrad3x3_c64_blocks", "vqa_bn_acc_words", "vqa_bn_apply_pool_chunks", "vqa_se_bwd_blocks", "vqa_wgrad3x3_c128_blocks", "vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks", "vqa_stem_conv_pool_ok", "vqa_wgrad3x3_c64_bn_ok"}   # return a count, not a status
+_NO_STATUS = _RET_LL | {"vqa_wgrad3x3_c64_blocks", "vqa_bn_acc_words", "vqa_bn_apply_pool_chunks", "vqa_se_bwd_blocks", "vqa_wgrad3x3_c128_blocks", "vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks", "vqa_stem_conv_pool_ok", "vqa_wgrad3x3_c64_bn_ok", "vqa_conv8p_ok"}   # return a count, not a status
 
 _lib = None
 

@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm_conv.hip", "cnn_ops.hip", "token_ops.hip", "stem_conv.hip", "conv_c64.hip", "input_ops.hip"]
+SOURCES = ["gemm_conv.hip", "cnn_ops.hip", "token_ops.hip", "stem_conv.hip", "conv_c64.hip", "input_ops.hip", "gemm8p.hip"]
 LIB = os.path.join(HERE, "libvqa_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

@@ -46,21 +46,42 @@ struct C64Params {
 // each block while the MFMA ring registers are dead) and walks pixels; SWZ16 selects the weight-gradient kernels' slot swizzle.
 // ------------------------------------------------------------------------------------------------
 namespace {
-template <bool SWZ16>
-__device__ __forceinline__ void patch_bn_relu(char* patch, int nrows, int W, int PWc, int ih0, int H, const float* cf, int tid) {
+template <bool SWZ16, int NROWS>
+__device__ __forceinline__ void patch_bn_relu(char* patch, int W, int PWc, int ih0, int H, const float* cf, int tid) {
   const int c8 = tid & 7, pc0 = 1 + (tid >> 3);
   float sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sc[j] = cf[c8 * 8 + j]; sh[j] = cf[64 + c8 * 8 + j]; }
-  for (int prow = 0; prow < nrows; ++prow) {
-    if ((unsigned)(ih0 + prow) >= (unsigned)H) continue;           // a padding row: stays zero
-    for (int pc = pc0; pc <= W; pc += 64) {
-      const int slot = c8 ^ (SWZ16 ? ((pc & 7) ^ (((pc >> 3) & 1) << 2)) : (pc & 7));
-      u32x4* a = reinterpret_cast<u32x4*>(patch + ((prow * PWc + pc) * 8 + slot) * 16);
-      Vec16<bf16_t> v, o; v.raw = *a;
+  // ROWS patch rows per batch: all their 16-byte reads are issued before the first value is used (a one-row-at-a-time loop was a chain
+  // of dependent LDS latencies: +33 us on the stage-1 forward conv, as much as the bn_apply pass it replaces)
+  constexpr int ROWS = NROWS <= 6 ? NROWS : (NROWS % 5 == 0 ? 5 : 2);
+  for (int pc = pc0; pc <= W; pc += 64) {
+    const int slot = c8 ^ (SWZ16 ? ((pc & 7) ^ (((pc >> 3) & 1) << 2)) : (pc & 7));
+    char* col = patch + (pc * 8 + slot) * 16;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float x = v.get(j) * sc[j] + sh[j]; o.set(j, x < 0.f ? 0.f : x); }
-      *a = o.raw;
+    for (int r0 = 0; r0 < NROWS; r0 += ROWS) {
+      Vec16<bf16_t> v[ROWS];
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) v[i].raw = *reinterpret_cast<const u32x4*>(col + (r0 + i) * PWc * 128);
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) {
+        if ((unsigned)(ih0 + r0 + i) >= (unsigned)H) continue;       // a padding row (first / last block of an image): stays zero
+        // 7 VALU per bf16 pair: 2 unpack, 2 fma, 2 v_maximum3_f32 (IEEE-2019 maximum: NaN-propagating like bn_apply's (x < 0 ? 0 : x);
+        // -0 becomes +0, equal as a number and as a conv operand), 1 v_cvt_pk_bf16_f32.  The element-wise get / set form compiled to
+        // ~2.5x that (per-element convert + bit-field insert) and made the prologue cost as much as the pass it replaces
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t w = v[i].raw[k];
+          float x0 = __builtin_fmaf(__uint_as_float(w << 16), sc[2 * k], sh[2 * k]);
+          float x1 = __builtin_fmaf(__uint_as_float(w & 0xffff0000u), sc[2 * k + 1], sh[2 * k + 1]);
+          x0 = __builtin_elementwise_maximum(x0, 0.f); x1 = __builtin_elementwise_maximum(x1, 0.f);
+          o[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){x0, x1}, bf16x2_t));
+        }
+        *reinterpret_cast<u32x4*>(col + (r0 + i) * PWc * 128) = o;
+      }
     }
   }
 }
@@ -298,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
     const unsigned pbase = lds0 + (unsigned)buf * (unsigned)(patch_elems * 2);
     const int b = blk / rblocks, oh0 = (blk - b * rblocks) * RBP;
     if (p.pre_mode) {                                               // normalise + ReLU the landed patch in place (LDS only: no vmcnt wait)
-      patch_bn_relu<false>(smem + (size_t)buf * (size_t)(patch_elems * 2), RBP + 2, p.W, PWc, oh0 - 1, p.H, cf, tid);
+      patch_bn_relu<false, RBP + 2>(smem + (size_t)buf * (size_t)(patch_elems * 2), p.W, PWc, oh0 - 1, p.H, cf, tid);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -625,7 +646,7 @@ __device__ __forceinline__ void wgrad_c64p_body(const C64WgradParams& p, char* s
     if (nxt < nblocks && !(p.dbg & 4)) issue(nxt, buf ^ 1);     // the other buffer: every wave finished reading it at the last barrier
     if (p.pre_coef) {                                           // normalise + ReLU the landed x patch in place (both wave groups take part)
       const int bq = blk / rblocks;
-      patch_bn_relu<true>(smem + buf * buf_bytes, RBW + 2, Wd, PWc, (blk - bq * rblocks) * RBW - 1, p.H, cf, tid);
+      patch_bn_relu<true, RBW + 2>(smem + buf * buf_bytes, Wd, PWc, (blk - bq * rblocks) * RBW - 1, p.H, cf, tid);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }

@@ -1,0 +1,456 @@
+// 256 x 256 x 64 bf16 GEMM tile with the 8-phase schedule of cdna_hip_programming.md section 5 ("The 256^2 8-phase template"),
+// written for this model's convolutions (round 4).  Why a second GEMM core beside igemm_kernel: that kernel is the guide's
+// "step-3 structure" (128^2 tile, 4 waves, one or two barriers per K step, 2 workgroups per CU), whose ceiling is ~0.9 PFLOP/s on
+// MI355X whatever is tuned inside it -- three rounds of tile / ring / schedule variants in gemm_conv.hip all landed at 0.82-1.04.
+// This structure is different in kind:
+//   * ONE 8-wave workgroup per CU, 2 (M) x 4 (N) waves, 128 x 64 outputs per wave = 32 accumulator tiles (128 VGPRs);
+//   * the two waves that share a SIMD belong to different M halves and run ONE BARRIER APART: while one issues its LDS reads and
+//     LDS-DMA pieces, its partner issues 16 MFMAs (one 64 x 32 quadrant of its outputs x K = 64) -- the matrix pipe of every SIMD
+//     always has a wave in its MFMA segment;
+//   * a K tile (64) is consumed in 4 phases (quadrants 00, 01, 11, 10); operands arrive as four 16 KB half-tiles per K tile
+//     (A rows needed first / second, B columns needed first / second), ONE half-tile staged per phase by LDS-DMA into a double
+//     buffer (8 x 16 KB = 128 KB), four half-tiles in flight, counted vmcnt waits, raw s_barrier (never vmcnt(0) in the loop);
+//   * LDS rows are 128 bytes, XOR-swizzled on the DMA source side (16-byte slot bit 1 ^= row bit 2) so a ds_read_b128 fragment
+//     read is 4-way instead of 8-way conflicted.
+// Hazard bookkeeping (phase p of K tile t = global phase 4t + p; group 1 = waves 4-7 runs one barrier behind group 0):
+//   staged in phase | half-tile      | its buffer was last read in | first read in
+//   P1(t)           | B second (t+1) | P2(t-1)                     | P2(t+1)   (waited for in P1(t+1))
+//   P2(t)           | A second (t+1) | P3(t-1)                     | P3(t+1)   (waited for in P2(t+1))
+//   P3(t)           | A first  (t+2) | P1(t)                       | P1(t+2)   (waited for in P4(t+1))
+//   P4(t)           | B first  (t+2) | P1(t)                       | P1(t+2)   (waited for in P4(t+1))
+// i.e. every buffer is restaged >= 2 phases after its last read (the guide's WAR rule incl. the one-barrier stagger) and read
+// one phase after the wait + barrier that retires its DMA (RAW rule); each wait is vmcnt(8): the wave's own 2 pieces of the four
+// youngest half-tiles stay in flight.
+#include "common.h"
+
+namespace {
+typedef int i32x4_g8 __attribute__((ext_vector_type(4)));
+constexpr int G8_BM = 256, G8_BN = 256, G8_BK = 64;
+constexpr int G8_HALF = 128 * 128;                   // bytes of a half-tile: 128 rows x 64 k x 2
+constexpr int G8_LDS = 8 * G8_HALF;                  // 2 buffers x {A first, A second, B first, B second}
+constexpr int OOB_G8 = (int)0x80000000;
+
+__device__ __forceinline__ void dma16_g8(i32x4_g8 rs, unsigned lds_addr, int voff, int soff) {
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_addr), "s"(soff) : "memory");
+}
+}  // namespace
+
+struct G8Params {
+  const bf16_t* A; const bf16_t* B; bf16_t* C;        // A [M][K], B [N][K] (both K-contiguous), C [M][N]
+  int M, N, K; unsigned a_bytes, b_bytes;
+  int tiles_n, ntiles;
+};
+
+// tile row (0 .. 255) of buffer row r0 (multiple of 8) of half-tile `which` (0 A first, 1 A second, 2 B first, 3 B second)
+__device__ __forceinline__ int g8_row_of(int which, int r0) {
+  if (which == 0) return r0 < 64 ? r0 : r0 + 64;                    // rows 0-63 | 128-191: the first 64 rows of each M half
+  if (which == 1) return r0 < 64 ? r0 + 64 : r0 + 128;              // rows 64-127 | 192-255
+  const int q = r0 >> 5, i = r0 & 31;                               // B: 32 of the 64 columns of each of the 4 column groups
+  return q * 64 + i + (which == 3 ? 32 : 0);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 2, wc = w & 3;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  // XCD-aware tile order (bijective form): consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a contiguous
+  // range of tiles (N fastest), so the tiles that share A rows / B columns meet in one L2
+  int tile;
+  {
+    const int nwg = (int)gridDim.x, orig = (int)blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * G8_BM, n0 = tn * G8_BN;
+  const unsigned long long aa = (unsigned long long)p.A, ba = (unsigned long long)p.B;
+  const i32x4_g8 rsA = {(int)(unsigned)aa, (int)((unsigned)(aa >> 32) & 0xffffu), (int)p.a_bytes, 0x00020000};
+  const i32x4_g8 rsB = {(int)(unsigned)ba, (int)((unsigned)(ba >> 32) & 0xffffu), (int)p.b_bytes, 0x00020000};
+
+  // ---- DMA plan: a piece = 8 buffer rows x 128 bytes; wave w stages pieces 2w, 2w+1 of every half-tile.  Lane: row dr of the piece,
+  //      LDS slot dc; the SOURCE chunk is dc ^ f(row), f = ((row >> 2) & 1) << 1 (the swizzle lives on the source side).
+  const int dr = lane >> 3, dc = lane & 7;
+  const int voff = dr * p.K * 2 + ((dc ^ (((dr >> 2) & 1) << 1)) << 4);
+  const int nkt = p.K / G8_BK;
+  auto stage = [&](int which, int t) {             // half-tile `which` of K tile t into buffer t & 1 (t >= nkt: out of range -> zeros)
+    const unsigned base = lds0 + (unsigned)(((t & 1) * 4 + which) * G8_HALF);
+    const bool ok = t < nkt;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pc = 2 * w + h, row = g8_row_of(which, pc * 8);
+      const int so = ((which < 2 ? m0 : n0) + row) * p.K * 2 + t * (G8_BK * 2);
+      dma16_g8(which < 2 ? rsA : rsB, base + (unsigned)(pc * 1024), ok ? voff : OOB_G8, ok ? so : 0);
+    }
+  };
+
+  // ---- fragment read addresses (bytes, relative to a half-tile buffer): row = (wave's first row) + 16 i + li, slot = (4 kk + g) ^ f
+  const int fl = ((li >> 2) & 1) << 1;
+  const unsigned ra = (unsigned)((wr * 64 + li) * 128 + ((g ^ fl) << 4));      // + i * 2048 + kk * 64
+  const unsigned rb = (unsigned)((wc * 32 + li) * 128 + ((g ^ fl) << 4));      // + j * 2048 + kk * 64
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 a0[4][2], a1[4][2], b0[2][2], b1[2][2];
+
+#define G8_RD(dst, which, off) dst = *reinterpret_cast<const bf16x8*>(smem + (d * 4 + (which)) * G8_HALF + (off))
+#define G8_BAR() __builtin_amdgcn_s_barrier()
+#define G8_MFMA(AF, BFR, MI, NJ)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)              \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                      \
+          acc[(MI) + i][(NJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFR[j][kk], AF[i][kk], acc[(MI) + i][(NJ) + j], 0, 0, 0)
+
+  // ---- prologue: K tile 0 complete + the first two half-tiles of K tile 1 (the steady-state lead)
+  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(2, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  // A first (0), B first (0) landed (this wave's pieces)
+  G8_BAR();
+  if (wr == 1) G8_BAR();                                            // group 1 runs one barrier behind group 0 from here on
+
+  for (int t = 0; t < nkt; ++t) {
+    const int d = t & 1;
+    // ---------------- P1: quadrant (0, 0)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) G8_RD(b0[j][kk], 2, rb + j * 2048 + kk * 64);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) G8_RD(a0[i][kk], 0, ra + i * 2048 + kk * 64);
+    stage(3, t + 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // B second (t) landed -> read in P2
+    G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    G8_MFMA(a0, b0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G8_BAR();
+    // ---------------- P2: quadrant (0, 1)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) G8_RD(b1[j][kk], 3, rb + j * 2048 + kk * 64);
+    stage(1, t + 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // A second (t) landed -> read in P3
+    G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    G8_MFMA(a0, b1, 0, 2);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G8_BAR();
+    // ---------------- P3: quadrant (1, 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) G8_RD(a1[i][kk], 1, ra + i * 2048 + kk * 64);
+    stage(0, t + 2);
+    G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    G8_MFMA(a1, b1, 4, 2);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G8_BAR();
+    // ---------------- P4: quadrant (1, 0)
+    stage(2, t + 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // A first, B first (t + 1) landed -> read in P1 of the next K tile
+    G8_BAR();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    G8_MFMA(a1, b0, 4, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G8_BAR();
+  }
+  if (wr == 0) G8_BAR();                                            // (group 0 waits for group 1's last barrier)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the out-of-range tail pieces
+#undef G8_RD
+#undef G8_MFMA
+
+  // ---- epilogue: acc[mi][nj][r] = C[m0 + 128 wr + 16 mi + li][n0 + 64 wc + 16 nj + 4 g + r]  (operands swapped: 4 consecutive columns per lane)
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const size_t row = (size_t)(m0 + wr * 128 + mi * 16 + li);
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+      const int col = n0 + wc * 64 + nj * 16 + 4 * g;
+      u32x2_t o;
+      o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[mi][nj][0], acc[mi][nj][1]}, bf16x2_t));
+      o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[mi][nj][2], acc[mi][nj][3]}, bf16x2_t));
+      *reinterpret_cast<u32x2_t*>(p.C + row * p.N + col) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same schedule as an implicit-GEMM 3x3 / stride 1 / pad 1 convolution (forward, or the data gradient with the packed
+// [Cin][(tap, Cout)] operand and mirrored taps), NHWC bf16, for the 14 x 14 and 7 x 7 stages of the model (256 and 512 channels).
+// TILE SHAPE = QUANTISATION: at B = 512 those layers have M = 100 352 / 25 088 output pixels; 256-row tiles give 392 / 196 tiles for
+// 256 CUs (one 128 KB workgroup per CU): 1.53 / 0.77 rounds, a quarter of the chip idle.  A tile of 196 output pixels (one 14 x 14
+// image, four 7 x 7 images) padded to 224 = 2 x 7 MFMA rows gives 512 / 256 tiles: exactly 2 / 1 rounds, for 12.5 % padded MFMAs.
+//   wave (wr, wc): rows 112 wr .. +112 (7 row tiles), columns 64 wc .. +64 (4 column tiles): 28 accumulator tiles
+//   A first  = tile rows 0-63 | 112-175 (4 row tiles per M half, 128 buffer rows), A second = rows 64-111 | 176-223 (3 row tiles, 96
+//   buffer rows; waves 6-7 stage out-of-range dummies so that every wave counts the same vmcnt);  phases 16 / 16 / 12 / 12 MFMAs.
+// A rows are gathered: a lane stages the same 4 tile rows for the whole launch, so their (b, oh, ow) are decoded once and a tap costs a
+// compare + add per piece; padding taps and rows beyond the tile's valid rows are out-of-range offsets (zeros from the range check).
+// Epilogue: the tile is rounded to bf16 and staged in LDS (528-byte rows), written out as full 512-byte row segments, and the BatchNorm
+// column sums (of the bf16 values, like igemm_kernel) are folded over the 16 row groups in a fixed order -> fixed-point accumulators.
+// ------------------------------------------------------------------------------------------------------------------
+struct C8Params {
+  const bf16_t* x; const bf16_t* w; bf16_t* out; unsigned long long* stats;
+  int M, N, K, B, H, W, C, transposed, rpt, tiles_n, ntiles, cpk_shift;
+  unsigned x_bytes, w_bytes;
+};
+namespace { constexpr int C8_BMP = 224, C8_LDC = 528; }
+
+__global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 2, wc = w & 3;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  int tile;
+  {
+    const int nwg = (int)gridDim.x, orig = (int)blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * p.rpt, n0 = tn * G8_BN;
+  const unsigned long long xa = (unsigned long long)p.x, wa = (unsigned long long)p.w;
+  const i32x4_g8 rsX = {(int)(unsigned)xa, (int)((unsigned)(xa >> 32) & 0xffffu), (int)p.x_bytes, 0x00020000};
+  const i32x4_g8 rsW = {(int)(unsigned)wa, (int)((unsigned)(wa >> 32) & 0xffffu), (int)p.w_bytes, 0x00020000};
+  const int nkt = p.K / G8_BK;
+  const int dr = lane >> 3, dc = lane & 7, slot = (dc ^ (((dr >> 2) & 1) << 1)) << 4;
+  const int HW = p.H * p.W;
+
+  // ---- this lane's four staged A rows: k = 2 * half + h  (half 0: A first, 1: A second; piece 2w + h)
+  int pixb[4], ohw[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int half = k >> 1, r = (2 * w + (k & 1)) * 8 + dr;
+    int R;
+    if (half == 0) R = r < 64 ? r : r + 48;                          // rows 0-63 | 112-175
+    else R = r < 48 ? 64 + r : (r < 96 ? 128 + r : C8_BMP);          // rows 64-111 | 176-223 | (pieces 12-15: none)
+    const int m = m0 + R;
+    if (R < p.rpt && m < p.M) {
+      const int b = m / HW, rem = m - b * HW, oh = rem / p.W, ow = rem - oh * p.W;
+      pixb[k] = ((b * p.H + oh) * p.W + ow) * p.C * 2 + slot;
+      ohw[k] = (oh << 16) | ow;
+    } else { pixb[k] = 0; ohw[k] = (int)0xc0000000; }                // oh = -16384: every tap fails the range test
+  }
+  const int voffB = dr * p.K * 2 + slot;
+  auto stage = [&](int which, int t) {
+    const unsigned base = lds0 + (unsigned)(((t & 1) * 4 + which) * G8_HALF);
+    const bool okt = t < nkt;
+    if (which < 2) {                                                 // A: gathered pixels of tap (t >> cpk_shift), channel chunk t & (cpk - 1)
+      const int tap = t >> p.cpk_shift, cc = t & ((1 << p.cpk_shift) - 1);
+      const int r = (tap * 11) >> 5, s_ = tap - 3 * r;
+      const int d_r = p.transposed ? 1 - r : r - 1, d_s = p.transposed ? 1 - s_ : s_ - 1;
+      const int dpix = (d_r * p.W + d_s) * p.C * 2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = which * 2 + h, ih = (ohw[k] >> 16) + d_r, iw = (ohw[k] & 0xffff) + d_s;
+        const bool ok = okt && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        dma16_g8(rsX, base + (unsigned)((2 * w + h) * 1024), ok ? pixb[k] + dpix : OOB_G8, okt ? cc * 128 : 0);   // (scalar offset: wave-uniform)
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pc = 2 * w + h, row = g8_row_of(which, pc * 8);
+        dma16_g8(rsW, base + (unsigned)(pc * 1024), okt ? voffB : OOB_G8, okt ? ((n0 + row) * p.K + t * G8_BK) * 2 : 0);
+      }
+    }
+  };
+
+  const int fl = ((li >> 2) & 1) << 1;
+  const unsigned ra0 = (unsigned)((wr * 64 + li) * 128 + ((g ^ fl) << 4));     // A first:  + i * 2048 + kk * 64, i < 4
+  const unsigned ra1 = (unsigned)((wr * 48 + li) * 128 + ((g ^ fl) << 4));     // A second: i < 3
+  const unsigned rb = (unsigned)((wc * 32 + li) * 128 + ((g ^ fl) << 4));
+
+  f32x4 acc[7][4];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 a0[4][2], a1[3][2], b0[2][2], b1[2][2];
+
+#define C8_RD(dst, which, off) dst = *reinterpret_cast<const bf16x8*>(smem + (d * 4 + (which)) * G8_HALF + (off))
+#define C8_MFMA(AF, NI, BFR, MI, NJ)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < (NI); ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)           \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                      \
+          acc[(MI) + i][(NJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFR[j][kk], AF[i][kk], acc[(MI) + i][(NJ) + j], 0, 0, 0)
+
+  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(2, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  G8_BAR();
+  if (wr == 1) G8_BAR();
+
+  for (int t = 0; t < nkt; ++t) {
+    const int d = t & 1;
+    // ---------------- P1: rows 0-63 of the wave x columns 0-31
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) C8_RD(b0[j][kk], 2, rb + j * 2048 + kk * 64);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) C8_RD(a0[i][kk], 0, ra0 + i * 2048 + kk * 64);
+    stage(3, t + 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    C8_MFMA(a0, 4, b0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G8_BAR();
+    // ---------------- P2: rows 0-63 x columns 32-63
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) C8_RD(b1[j][kk], 3, rb + j * 2048 + kk * 64);
+    stage(1, t + 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    C8_MFMA(a0, 4, b1, 0, 2);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G8_BAR();
+    // ---------------- P3: rows 64-111 x columns 32-63
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) C8_RD(a1[i][kk], 1, ra1 + i * 2048 + kk * 64);
+    stage(0, t + 2);
+    G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    C8_MFMA(a1, 3, b1, 4, 2);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G8_BAR();
+    // ---------------- P4: rows 64-111 x columns 0-31
+    stage(2, t + 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    G8_BAR();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    C8_MFMA(a1, 3, b0, 4, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G8_BAR();
+  }
+  if (wr == 0) G8_BAR();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the out-of-range tail pieces have written their zeros
+  G8_BAR();
+#undef C8_RD
+#undef C8_MFMA
+
+  // ---- epilogue 1: bf16 tile -> LDS  (acc[mi][nj][r] = out[row 112 wr + 16 mi + li][column 64 wc + 16 nj + 4 g + r])
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+#pragma unroll
+  for (int mi = 0; mi < 7; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+      u32x2_t o;
+      o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[mi][nj][0], acc[mi][nj][1]}, bf16x2_t));
+      o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[mi][nj][2], acc[mi][nj][3]}, bf16x2_t));
+      *reinterpret_cast<u32x2_t*>(smem + (wr * 112 + mi * 16 + li) * C8_LDC + (wc * 64 + nj * 16 + 4 * g) * 2) = o;
+    }
+  __syncthreads();
+  // ---- epilogue 2: full 512-byte row segments out; column sums of the stored (bf16) values
+  const int c16 = tid & 31, rg = tid >> 5;
+  float cs[8], cq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
+  const int rows = min(p.rpt, p.M - m0);
+  for (int R = rg; R < rows; R += 16) {
+    Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + R * C8_LDC + c16 * 16);
+    *reinterpret_cast<u32x4*>(p.out + (size_t)(m0 + R) * p.N + n0 + c16 * 8) = v.raw;
+    if (p.stats) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = v.get(j); cs[j] += f; cq[j] += f * f; }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();                                                // the staged tile has been read: its LDS is reused for the partial sums
+    float* part = reinterpret_cast<float*>(smem);                   // [16 row groups][2][256]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { part[(rg * 2 + 0) * 256 + c16 * 8 + j] = cs[j]; part[(rg * 2 + 1) * 256 + c16 * 8 + j] = cq[j]; }
+    __syncthreads();
+    const int k = tid >> 8, c = tid & 255;                          // 512 threads = 2 sums x 256 columns
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part[(q * 2 + k) * 256 + c];
+    const int Rr = acc_replicas(p.N);
+    acc_add_fixed(p.stats, (size_t)Rr * 2 * p.N, (size_t)(tm % Rr) * 2 * p.N + (size_t)k * p.N + n0 + c, t);
+  }
+}
+
+extern "C" {
+// C[M][N] = A[M][K] . B[N][K]^T, bf16 in / fp32 accumulate / bf16 out.  M % 256 == 0, N % 256 == 0, K % 64 == 0.
+int vqa_gemm8p(const void* A, const void* B, void* C, int M, int N, int K, hipStream_t st) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || M % G8_BM || N % G8_BN || K % G8_BK) return VQA_EARG;
+  const size_t ab = (size_t)M * K * 2, bb = (size_t)N * K * 2;
+  if (ab >= 0x7fffffffull || bb >= 0x7fffffffull) return VQA_EARG;
+  G8Params p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C; p.M = M; p.N = N; p.K = K;
+  p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+  p.tiles_n = N / G8_BN; p.ntiles = (M / G8_BM) * p.tiles_n;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS); attr = true; }
+  hipLaunchKernelGGL(gemm8p_kernel, dim3(p.ntiles), dim3(512), G8_LDS, st, p);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+// 1: vqa_conv8p takes the shape (3x3 / stride 1 / pad 1, NHWC bf16, C a power-of-two multiple of 64, N a multiple of 256)
+int vqa_conv8p_ok(int B, int H, int W, int C, int N) {
+  if (B <= 0 || H <= 0 || W <= 0 || H > 16383 || W > 16383 || C < 64 || (C & (C - 1)) || N <= 0 || N % G8_BN) return 0;
+  const size_t xb = (size_t)B * H * W * C * 2, wb = (size_t)N * 9 * C * 2;
+  if (xb >= 0x7fffffffull || wb >= 0x7fffffffull || (size_t)B * H * W >= 0x7fffffffull / 2) return 0;
+  return 1;
+}
+// out[B*H*W][N] = conv3x3(x [B][H][W][C], w [N][(r, s, c)]) (transposed = 0), or the stride-1 data gradient (transposed = 1: x is dy
+// [B][H][W][Cout], w the packed [Cin][(tap, Cout)] operand of vqa_pack_transpose, taps mirrored).  stats: fixed-point BatchNorm
+// accumulator (vqa_bn_acc_words(2, N), caller-zeroed) receiving sum y | sum y^2 of the stored values, or NULL.
+int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stats, int B, int H, int W, int C, int N, int transposed,
+               hipStream_t st) {
+  if (!x || !w || !out || !vqa_conv8p_ok(B, H, W, C, N)) return VQA_EARG;
+  C8Params p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
+  p.M = B * H * W; p.N = N; p.K = 9 * C; p.B = B; p.H = H; p.W = W; p.C = C; p.transposed = transposed;
+  p.x_bytes = (unsigned)((size_t)B * H * W * C * 2); p.w_bytes = (unsigned)((size_t)N * 9 * C * 2);
+  // valid rows per 224-row tile: 196 (= one 14 x 14 image / four 7 x 7 images: 512 / 256 tiles at B = 512) when that divides M, else all 224
+  p.rpt = (p.M % 196 == 0) ? 196 : C8_BMP;
+  p.tiles_n = N / G8_BN;
+  const int tiles_m = (p.M + p.rpt - 1) / p.rpt;
+  if (stats && tiles_m > VQA_ACC_MAX_PARTS) return VQA_EARG;
+  p.ntiles = tiles_m * p.tiles_n;
+  p.cpk_shift = 0;
+  while ((64 << p.cpk_shift) < C) ++p.cpk_shift;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS); attr = true; }
+  hipLaunchKernelGGL(conv8p_kernel, dim3(p.ntiles), dim3(512), G8_LDS, st, p);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+}

@@ -199,6 +199,24 @@ def wgrad3x3_c64_bn(y, coef, dy, dw, B, H, W):
         PROFILE.append(("wgrad3x3_c64", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
 
 
+def conv8p_ok(B, H, W, C, N) -> bool:
+    return L.count("vqa_conv8p_ok", B, H, W, C, N) > 0
+
+
+def conv8p(x, w, B, H, W, C, N, *, transposed=0, stats_acc=None, out=None):
+    """3x3 / 1 / pad 1 conv (or its stride-1 data gradient) on the 8-phase 224(196) x 256 x 64 tile (csrc/gemm8p.hip).  bf16 NHWC."""
+    if out is None:
+        out = torch.empty((B * H * W, N), device=x.device, dtype=torch.bfloat16)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_conv8p", ptr(x), ptr(w), ptr(out), ptr(stats_acc), B, H, W, C, N, int(transposed))
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("conv8p_kernel", 2.0 * B * H * W * N * 9 * C, e0, e1, (B * H * W * (C + N) + N * 9 * C) * 2))
+    return out
+
+
 def c64w_blocks(B, H, W) -> int:
     """Slabs vqa_wgrad3x3_c64 wants (8-wave LDS-DMA kernel: 4 or 2 rows per block; else the 4-wave kernel); 0: unsupported shape."""
     return L.count("vqa_wgrad3x3_c64_blocks", B, H, W)
