@@ -64,6 +64,19 @@ def test_conv8p_matches_aten(B, H, W, C, N, transposed):
     geom = (B, H, W, C, H, W, 3, 3, 1, 1)
     o2, _, _ = K.igemm(x, (wq.to(DEV).view(N, 9 * C) if not transposed else wt.view(N, 9 * C)), B * H * W, N, 9 * C, geom, dtype=bf, transposed=transposed)
     assert (out.float() - o2.float()).abs().max().item() <= 1.6e-2 * max(1.0, float(o2.float().abs().max()))
+    if transposed:
+        # the epilogue of the identity-path data gradient: (conv + addend * (addmask > 0)) * (outmask > 0), bit-equal to igemm's on the same conv value
+        add = torch.randn(B * H * W, N, generator=g).to(DEV, bf)
+        am = torch.randn(B * H * W, N, generator=g).to(DEV, bf)
+        om = torch.randn(B * H * W, N, generator=g).to(DEV, bf)
+        for kw in (dict(addend=add), dict(addend=add, addmask=am), dict(outmask=om), dict(addend=add, addmask=am, outmask=om)):
+            o3 = K.conv8p(x, wt.view(N, 9 * C), B, H, W, C, N, transposed=1, **kw)
+            e = out.float()
+            if "addend" in kw:
+                e = (e + (add.float() * (am.float() > 0) if "addmask" in kw else add.float())).to(bf).float()
+            if "outmask" in kw:
+                e = e * (om.float() > 0)
+            assert torch.equal(o3.float(), e), kw.keys()
     if not transposed:
         R = max(1, min(8, 512 // N))
         sums, flag = _acc_decode(acc, R, 2, N)

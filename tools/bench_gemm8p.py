@@ -20,7 +20,7 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-for M, N, Kd in [(4096, 4096, 4096), (8192, 8192, 8192), (100352, 256, 2304), (65536, 256, 2304), (25088, 512, 4608), (401408, 256, 1152)]:
+for M, N, Kd in [(4096, 4096, 4096), (8192, 8192, 8192), (100352, 256, 2304), (65536, 256, 2304)]:
     A = torch.randn(M, Kd, device=dev).to(bf)
     B = torch.randn(N, Kd, device=dev).to(bf)
     C = torch.empty(M, N, device=dev, dtype=bf)

@@ -51,6 +51,8 @@ __device__ __forceinline__ int g8_row_of(int which, int r0) {
   return q * 64 + i + (which == 3 ? 32 : 0);
 }
 
+// (Measured and rejected, round 4: issuing the phase's two LDS-DMA pieces in the MIDDLE of its MFMA segment with vmcnt(6) waits --
+// 1112 vs 1220 TFLOP/s at 4096^3, 141 vs 128 us on the stage-3 conv: profiles/r04_gemm8p_bench.txt.)
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
@@ -99,10 +101,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
 
 #define G8_RD(dst, which, off) dst = *reinterpret_cast<const bf16x8*>(smem + (d * 4 + (which)) * G8_HALF + (off))
 #define G8_BAR() __builtin_amdgcn_s_barrier()
-#define G8_MFMA(AF, BFR, MI, NJ)                                                                            \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)              \
+#define G8_MFMA_R(AF, BFR, MI, NJ, I0, I1)                                                                  \
+  _Pragma("unroll") for (int i = (I0); i < (I1); ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)        \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                      \
           acc[(MI) + i][(NJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFR[j][kk], AF[i][kk], acc[(MI) + i][(NJ) + j], 0, 0, 0)
+#define G8_WAIT() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+// one phase's compute segment
+#define G8_COMPUTE(AF, BFR, MI, NJ, NI)                                                                     \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                            \
+  G8_MFMA_R(AF, BFR, MI, NJ, 0, NI);                                                                        \
+  __builtin_amdgcn_s_setprio(0);                                                                            \
+  __builtin_amdgcn_sched_barrier(0)
 
   // ---- prologue: K tile 0 complete + the first two half-tiles of K tile 1 (the steady-state lead)
   stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(2, 1);
@@ -123,14 +133,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) G8_RD(a0[i][kk], 0, ra + i * 2048 + kk * 64);
     stage(3, t + 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // B second (t) landed -> read in P2
+    G8_WAIT();                                                      // B second (t) landed -> read in P2
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    G8_MFMA(a0, b0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    G8_COMPUTE(a0, b0, 0, 0, 4);
     G8_BAR();
     // ---------------- P2: quadrant (0, 1)
 #pragma unroll
@@ -138,14 +144,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) G8_RD(b1[j][kk], 3, rb + j * 2048 + kk * 64);
     stage(1, t + 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // A second (t) landed -> read in P3
+    G8_WAIT();                                                      // A second (t) landed -> read in P3
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    G8_MFMA(a0, b1, 0, 2);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    G8_COMPUTE(a0, b1, 0, 2, 4);
     G8_BAR();
     // ---------------- P3: quadrant (1, 1)
 #pragma unroll
@@ -155,27 +157,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
     stage(0, t + 2);
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    G8_MFMA(a1, b1, 4, 2);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    G8_COMPUTE(a1, b1, 4, 2, 4);
     G8_BAR();
     // ---------------- P4: quadrant (1, 0)
     stage(2, t + 2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // A first, B first (t + 1) landed -> read in P1 of the next K tile
+    G8_WAIT();                                                      // A first, B first (t + 1) landed -> read in P1 of the next K tile
     G8_BAR();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    G8_MFMA(a1, b0, 4, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    G8_COMPUTE(a1, b0, 4, 0, 4);
     G8_BAR();
   }
   if (wr == 0) G8_BAR();                                            // (group 0 waits for group 1's last barrier)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the out-of-range tail pieces
 #undef G8_RD
-#undef G8_MFMA
 
   // ---- epilogue: acc[mi][nj][r] = C[m0 + 128 wr + 16 mi + li][n0 + 64 wc + 16 nj + 4 g + r]  (operands swapped: 4 consecutive columns per lane)
   typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -211,6 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
 // ------------------------------------------------------------------------------------------------------------------
 struct C8Params {
   const bf16_t* x; const bf16_t* w; bf16_t* out; unsigned long long* stats;
+  const bf16_t* addend; const bf16_t* addmask; const bf16_t* outmask;   // epilogue inputs [M][N] or NULL (as vqa_igemm)
   int M, N, K, B, H, W, C, transposed, rpt, tiles_n, ntiles, cpk_shift;
   unsigned x_bytes, w_bytes;
 };
@@ -251,20 +245,25 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     } else { pixb[k] = 0; ohw[k] = (int)0xc0000000; }                // oh = -16384: every tap fails the range test
   }
   const int voffB = dr * p.K * 2 + slot;
+  int voffA[4] = {OOB_G8, OOB_G8, OOB_G8, OOB_G8};
   auto stage = [&](int which, int t) {
     const unsigned base = lds0 + (unsigned)(((t & 1) * 4 + which) * G8_HALF);
     const bool okt = t < nkt;
     if (which < 2) {                                                 // A: gathered pixels of tap (t >> cpk_shift), channel chunk t & (cpk - 1)
       const int tap = t >> p.cpk_shift, cc = t & ((1 << p.cpk_shift) - 1);
-      const int r = (tap * 11) >> 5, s_ = tap - 3 * r;
-      const int d_r = p.transposed ? 1 - r : r - 1, d_s = p.transposed ? 1 - s_ : s_ - 1;
-      const int dpix = (d_r * p.W + d_s) * p.C * 2;
+      if (cc == 0) {                                                 // a new tap (scalar branch, every C / 64 K tiles): this half's two source offsets
+        const int r = (tap * 11) >> 5, s_ = tap - 3 * r;
+        const int d_r = p.transposed ? 1 - r : r - 1, d_s = p.transposed ? 1 - s_ : s_ - 1;
+        const int dpix = (d_r * p.W + d_s) * p.C * 2;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = which * 2 + h, ih = (ohw[k] >> 16) + d_r, iw = (ohw[k] & 0xffff) + d_s;
-        const bool ok = okt && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        dma16_g8(rsX, base + (unsigned)((2 * w + h) * 1024), ok ? pixb[k] + dpix : OOB_G8, okt ? cc * 128 : 0);   // (scalar offset: wave-uniform)
+        for (int h = 0; h < 2; ++h) {
+          const int k = which * 2 + h, ih = (ohw[k] >> 16) + d_r, iw = (ohw[k] & 0xffff) + d_s;
+          voffA[k] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? pixb[k] + dpix : OOB_G8;
+        }
       }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        dma16_g8(rsX, base + (unsigned)((2 * w + h) * 1024), okt ? voffA[which * 2 + h] : OOB_G8, okt ? cc * 128 : 0);
     } else {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -287,11 +286,6 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   bf16x8 a0[4][2], a1[3][2], b0[2][2], b1[2][2];
 
 #define C8_RD(dst, which, off) dst = *reinterpret_cast<const bf16x8*>(smem + (d * 4 + (which)) * G8_HALF + (off))
-#define C8_MFMA(AF, NI, BFR, MI, NJ)                                                                        \
-  _Pragma("unroll") for (int i = 0; i < (NI); ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)           \
-      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                      \
-          acc[(MI) + i][(NJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFR[j][kk], AF[i][kk], acc[(MI) + i][(NJ) + j], 0, 0, 0)
-
   stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(2, 1);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   G8_BAR();
@@ -310,14 +304,10 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD(a0[i][kk], 0, ra0 + i * 2048 + kk * 64);
     stage(3, t + 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    G8_WAIT();
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    C8_MFMA(a0, 4, b0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    G8_COMPUTE(a0, b0, 0, 0, 4);
     G8_BAR();
     // ---------------- P2: rows 0-63 x columns 32-63
 #pragma unroll
@@ -325,14 +315,10 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD(b1[j][kk], 3, rb + j * 2048 + kk * 64);
     stage(1, t + 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    G8_WAIT();
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    C8_MFMA(a0, 4, b1, 0, 2);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    G8_COMPUTE(a0, b1, 0, 2, 4);
     G8_BAR();
     // ---------------- P3: rows 64-111 x columns 32-63
 #pragma unroll
@@ -342,28 +328,19 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     stage(0, t + 2);
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    C8_MFMA(a1, 3, b1, 4, 2);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    G8_COMPUTE(a1, b1, 4, 2, 3);
     G8_BAR();
     // ---------------- P4: rows 64-111 x columns 0-31
     stage(2, t + 2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    G8_WAIT();
     G8_BAR();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    C8_MFMA(a1, 3, b0, 4, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    G8_COMPUTE(a1, b0, 4, 0, 3);
     G8_BAR();
   }
   if (wr == 0) G8_BAR();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the out-of-range tail pieces have written their zeros
   G8_BAR();
 #undef C8_RD
-#undef C8_MFMA
 
   // ---- epilogue 1: bf16 tile -> LDS  (acc[mi][nj][r] = out[row 112 wr + 16 mi + li][column 64 wc + 16 nj + 4 g + r])
   typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -385,12 +362,56 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
   const int rows = min(p.rpt, p.M - m0);
-  for (int R = rg; R < rows; R += 16) {
-    Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + R * C8_LDC + c16 * 16);
-    *reinterpret_cast<u32x4*>(p.out + (size_t)(m0 + R) * p.N + n0 + c16 * 8) = v.raw;
-    if (p.stats) {
+  const bool fused = p.addend != nullptr || p.outmask != nullptr;
+  if (!fused) {
+    for (int R = rg; R < rows; R += 16) {
+      Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + R * C8_LDC + c16 * 16);
+      *reinterpret_cast<u32x4*>(p.out + (size_t)(m0 + R) * p.N + n0 + c16 * 8) = v.raw;
+      if (p.stats) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = v.get(j); cs[j] += f; cq[j] += f * f; }
+        for (int j = 0; j < 8; ++j) { const float f = v.get(j); cs[j] += f; cq[j] += f * f; }
+      }
+    }
+  } else {
+    // out = (conv + addend * (addmask > 0)) * (outmask > 0) on the staged bf16 value, like igemm_kernel's epilogue (the identity-path
+    // gradient and the ReLU masks of the data gradients, engine._block_bwd); two rows per step, every load ahead of the first store
+    for (int R = rg; R < rows; R += 32) {
+      Vec16<bf16_t> av[2], mv[2], ov[2];
+      bool live[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        live[i] = R + 16 * i < rows;
+        const size_t off = (size_t)(m0 + R + 16 * i) * p.N + n0 + c16 * 8;
+        if (live[i]) {
+          if (p.addend) av[i] = ldg16(p.addend + off);
+          if (p.addend && p.addmask) mv[i] = ldg16(p.addmask + off);
+          if (p.outmask) ov[i] = ldg16(p.outmask + off);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!live[i]) continue;
+        const size_t off = (size_t)(m0 + R + 16 * i) * p.N + n0 + c16 * 8;
+        Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + (R + 16 * i) * C8_LDC + c16 * 16);
+        if (p.addend) {
+          if (p.addmask) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v.set(j, v.get(j) + (mv[i].get(j) > 0.f ? av[i].get(j) : 0.f));
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v.set(j, v.get(j) + av[i].get(j));
+          }
+        }
+        if (p.outmask) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (!(ov[i].get(j) > 0.f)) v.set(j, 0.f);
+        }
+        stg16(p.out + off, v);
+        if (p.stats) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float f = v.get(j); cs[j] += f; cq[j] += f * f; }
+        }
+      }
     }
   }
   if (p.stats) {
@@ -433,11 +454,14 @@ int vqa_conv8p_ok(int B, int H, int W, int C, int N) {
 // out[B*H*W][N] = conv3x3(x [B][H][W][C], w [N][(r, s, c)]) (transposed = 0), or the stride-1 data gradient (transposed = 1: x is dy
 // [B][H][W][Cout], w the packed [Cin][(tap, Cout)] operand of vqa_pack_transpose, taps mirrored).  stats: fixed-point BatchNorm
 // accumulator (vqa_bn_acc_words(2, N), caller-zeroed) receiving sum y | sum y^2 of the stored values, or NULL.
-int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stats, int B, int H, int W, int C, int N, int transposed,
-               hipStream_t st) {
+// addend / addmask / outmask [B*H*W][N] bf16 or NULL: out = (conv + addend * (addmask > 0)) * (outmask > 0), the epilogue of vqa_igemm.
+int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stats, const void* addend, const void* addmask, const void* outmask,
+               int B, int H, int W, int C, int N, int transposed, hipStream_t st) {
   if (!x || !w || !out || !vqa_conv8p_ok(B, H, W, C, N)) return VQA_EARG;
   C8Params p;
+  if (addmask && !addend) return VQA_EARG;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
+  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.outmask = (const bf16_t*)outmask;
   p.M = B * H * W; p.N = N; p.K = 9 * C; p.B = B; p.H = H; p.W = W; p.C = C; p.transposed = transposed;
   p.x_bytes = (unsigned)((size_t)B * H * W * C * 2); p.w_bytes = (unsigned)((size_t)N * 9 * C * 2);
   // valid rows per 224-row tile: 196 (= one 14 x 14 image / four 7 x 7 images: 512 / 256 tiles at B = 512) when that divides M, else all 224

@@ -101,6 +101,10 @@ class HipEngine:
         # round 4: stage-1 conv1 -> bn1 -> relu -> conv2 without the normalised tensor a1: conv2 (8-wave patch kernel) and its weight
         # gradient take conv1's raw output and apply scale / shift / ReLU to their LDS patch (one bn_apply pass less per block)
         self.fuse_bn_conv = True
+        # round 4: 3x3 / stride-1 convs and data gradients with >= 256 output channels (stages 3, 4) on the 8-phase 224 x 256 tile
+        # (csrc/gemm8p.hip: one 8-wave workgroup per CU, staggered wave groups; 196-of-224-row tiles = exact rounds at B = 512)
+        self.use_conv8p = True
+        self.use_conv8p_bwd = True                # ... also for the data gradients (they run beside the weight-gradient stream)
         self._accbuf = None
         self._accpos = 0
         self._stem_fcoef = None
@@ -277,6 +281,10 @@ class HipEngine:
         return (self.dtype == torch.bfloat16 and Cin == 64 and Cout == 64 and R == 3 and stride == 1 and K.c64p_blocks(B, H, W) > 0
                 and self.use_c64p)
 
+    def _c8p_ok(self, B, H, W, Cin, Cout, R, stride, pad):
+        """3x3 / 1 / pad 1 conv (or stride-1 data gradient) the 8-phase tile takes: bf16, channels a power-of-two multiple of 64, >= 256 outputs."""
+        return (self.use_conv8p and self.dtype == torch.bfloat16 and R == 3 and stride == 1 and pad == 1 and K.conv8p_ok(B, H, W, Cin, Cout))
+
     def _wflip(self, name):                  # [Cin][(2-r,2-s)][Cout] operand of the stride-1 data gradient as a plain 3x3 conv
         e = self.E[name]
         n, c = e.shape[0], e.shape[1]
@@ -295,6 +303,10 @@ class HipEngine:
         if self._c64_ok(B, H, W, Cin, Cout, R, stride):
             y, st, mt = K.conv3x3_c64(x, self.Wm(wname), B, H, W, want_stats=stats)
             return y, st, mt, geom, Ho, Wo
+        if self._c8p_ok(B, H, W, Cin, Cout, R, stride, pad) and (acc or not stats):
+            a = self._acc(K.L.count("vqa_bn_acc_words", 2, Cout)) if stats else None
+            y = K.conv8p(x, self.Wm(wname), B, H, W, Cin, Cout, stats_acc=a)
+            return y, a, (-1 if a is not None else 0), geom, Ho, Wo
         a = self._acc(K.L.count("vqa_bn_acc_words", 2, Cout)) if (acc and stats) else None
         y, st, mt = K.igemm(x, self.Wm(wname), M, Cout, R * R * Cin, geom, dtype=self.dtype, want_stats=stats, stats_acc=a)
         return y, st, (-1 if a is not None else mt), geom, Ho, Wo
@@ -1038,6 +1050,8 @@ class HipEngine:
             da1, _, _ = K.conv3x3_c64p(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
         elif c64_2:
             da1, _, _ = K.conv3x3_c64(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
+        elif self.use_conv8p_bwd and self._c8p_ok(B, Ho, Wo, Cout, Cout, 3, 1, 1):
+            da1 = K.conv8p(dy2, self.Wt(p + ".conv2.weight"), B, Ho, Wo, Cout, Cout, transposed=1)
         else:
             geom_d2 = (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
             da1, _, _ = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1)
@@ -1068,6 +1082,8 @@ class HipEngine:
                 dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1, addend=dxd)
         elif c64_1 and not masked and outmask is None:
             dx, _, _ = K.conv3x3_c64(dy1, self._wflip(p + ".conv1.weight"), B, H, W, addend=dout, addmask=rec["out"])
+        elif self.use_conv8p_bwd and self._c8p_ok(B, H, W, Cout, Cin, 3, stride, 1):
+            dx = K.conv8p(dy1, self.Wt(p + ".conv1.weight"), B, H, W, Cout, Cin, transposed=1, addend=dout, addmask=out_act, outmask=outmask)
         else:
             dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
                                addend=dout, addmask=out_act, outmask=outmask)
