@@ -34,7 +34,8 @@ def _acc_decode(acc, R, K, C):
 
 
 @pytest.mark.parametrize("B,H,W,C,N", [(4, 14, 14, 256, 256), (8, 7, 7, 512, 512), (3, 14, 14, 256, 256), (5, 7, 7, 512, 512), (2, 28, 28, 128, 256),
-                                       (1, 5, 9, 64, 256), (16, 14, 14, 256, 256)])
+                                       (1, 5, 9, 64, 256), (16, 14, 14, 256, 256),
+                                       (2, 28, 28, 128, 128), (3, 28, 28, 128, 128), (1, 6, 10, 64, 128), (5, 7, 7, 128, 384)])
 @pytest.mark.parametrize("transposed", [0, 1])
 def test_conv8p_matches_aten(B, H, W, C, N, transposed):
     """Forward: conv2d(x, w, padding=1).  transposed: the stride-1 data gradient dx = conv_transpose2d(dy, w) through the packed

@@ -208,12 +208,33 @@ struct C8Params {
   int M, N, K, B, H, W, C, transposed, rpt, tiles_n, ntiles, cpk_shift;
   unsigned x_bytes, w_bytes;
 };
-namespace { constexpr int C8_BMP = 224, C8_LDC = 528; }
 
+// Wave layout WM (M) x WN (N), WM * WN = 8, every wave 112 rows x 64 columns:
+//   2 x 4: tile 224 x 256 (N a multiple of 256: the 256- and 512-channel stages), 196 valid rows;
+//   4 x 2: tile 448 x 128 (N = 128: the 128-channel stage, 28 x 28 maps: 392 valid rows = half an image, 1024 tiles = 4 rounds at B = 512).
+// SIMD partners are waves w and w + 4: the stagger groups are w < 4 / w >= 4 in both layouts (2 x 4: wm = w >> 2; 4 x 2: wm = w >> 1).
+template <int WM, int WN>
+struct C8Geo {
+  static constexpr int BMP = WM * 112, BN = WN * 64;
+  static constexpr int AF_ROWS = WM * 64, AS_ROWS = WM * 48, B_ROWS = WN * 32;
+  static constexpr int N_AF = AF_ROWS / 64, N_AS = (AS_ROWS / 8 + 7) / 8, N_B = (B_ROWS / 8 + 7) / 8;      // DMA pieces per wave and half-tile
+  // a half-tile's LDS region holds EVERY piece the 8 waves issue for it, the out-of-range dummies included (an out-of-range LDS-DMA still
+  // writes its zeros: 2 x 4 layout, A second = 12 real pieces + 4 dummies of waves 6-7)
+  static constexpr int AF_B = N_AF * 8192, AS_B = N_AS * 8192, BH_B = N_B * 8192;
+  static constexpr int OFF_AF = 0, OFF_AS = AF_B, OFF_BF = AF_B + AS_B, OFF_BS = AF_B + AS_B + BH_B, BUF = AF_B + AS_B + 2 * BH_B;
+  static constexpr int INFLIGHT = N_AF + N_AS + 2 * N_B;                                                   // pieces of the four youngest half-tiles
+  static constexpr int LDC = BN * 2 + 16, CPR = BN / 8, RG = 512 / CPR;                                     // epilogue staging
+  static constexpr int LDS = 2 * BUF > BMP * LDC ? 2 * BUF : BMP * LDC;
+  static_assert(LDS <= 160 * 1024 && RG * 2 * BN * 4 <= LDS && 2 * BN <= 512, "LDS budget");
+};
+
+template <int WM, int WN>
 __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
+  using G = C8Geo<WM, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 2, wc = w & 3;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = WM == 2 ? w >> 2 : w >> 1, wn = WM == 2 ? w & 3 : w & 1, grp = w >> 2;
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
   int tile;
   {
@@ -221,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-  const int m0 = tm * p.rpt, n0 = tn * G8_BN;
+  const int m0 = tm * p.rpt, n0 = tn * G::BN;
   const unsigned long long xa = (unsigned long long)p.x, wa = (unsigned long long)p.w;
   const i32x4_g8 rsX = {(int)(unsigned)xa, (int)((unsigned)(xa >> 32) & 0xffffu), (int)p.x_bytes, 0x00020000};
   const i32x4_g8 rsW = {(int)(unsigned)wa, (int)((unsigned)(wa >> 32) & 0xffffu), (int)p.w_bytes, 0x00020000};
@@ -229,15 +250,18 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   const int dr = lane >> 3, dc = lane & 7, slot = (dc ^ (((dr >> 2) & 1) << 1)) << 4;
   const int HW = p.H * p.W;
 
-  // ---- this lane's four staged A rows: k = 2 * half + h  (half 0: A first, 1: A second; piece 2w + h)
-  int pixb[4], ohw[4];
+  // ---- this lane's staged A rows: piece pc = w * N + h of A first (h < N_AF) and A second (h < N_AS); decoded once
+  constexpr int NA = G::N_AF + G::N_AS;
+  int pixb[NA], ohw[NA], voffA[NA];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int half = k >> 1, r = (2 * w + (k & 1)) * 8 + dr;
+  for (int k = 0; k < NA; ++k) {
+    const bool second = k >= G::N_AF;
+    const int r = ((second ? w * G::N_AS + (k - G::N_AF) : w * G::N_AF + k)) * 8 + dr;      // buffer row
     int R;
-    if (half == 0) R = r < 64 ? r : r + 48;                          // rows 0-63 | 112-175
-    else R = r < 48 ? 64 + r : (r < 96 ? 128 + r : C8_BMP);          // rows 64-111 | 176-223 | (pieces 12-15: none)
+    if (!second) R = (r / 64) * 112 + (r % 64);                                             // first 64 rows of each M group
+    else R = r < G::AS_ROWS ? (r / 48) * 112 + 64 + (r % 48) : G::BMP;                      // the other 48 (pieces beyond: none)
     const int m = m0 + R;
+    voffA[k] = OOB_G8;
     if (R < p.rpt && m < p.M) {
       const int b = m / HW, rem = m - b * HW, oh = rem / p.W, ow = rem - oh * p.W;
       pixb[k] = ((b * p.H + oh) * p.W + ow) * p.C * 2 + slot;
@@ -245,38 +269,41 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     } else { pixb[k] = 0; ohw[k] = (int)0xc0000000; }                // oh = -16384: every tap fails the range test
   }
   const int voffB = dr * p.K * 2 + slot;
-  int voffA[4] = {OOB_G8, OOB_G8, OOB_G8, OOB_G8};
-  auto stage = [&](int which, int t) {
-    const unsigned base = lds0 + (unsigned)(((t & 1) * 4 + which) * G8_HALF);
+  auto stage = [&](int which, int t) {                               // which: 0 A first, 1 A second, 2 B first, 3 B second
+    const unsigned base = lds0 + (unsigned)((t & 1) * G::BUF + (which == 0 ? G::OFF_AF : which == 1 ? G::OFF_AS : which == 2 ? G::OFF_BF : G::OFF_BS));
     const bool okt = t < nkt;
     if (which < 2) {                                                 // A: gathered pixels of tap (t >> cpk_shift), channel chunk t & (cpk - 1)
       const int tap = t >> p.cpk_shift, cc = t & ((1 << p.cpk_shift) - 1);
-      if (cc == 0) {                                                 // a new tap (scalar branch, every C / 64 K tiles): this half's two source offsets
+      const int k0 = which ? G::N_AF : 0, nk = which ? G::N_AS : G::N_AF;
+      if (cc == 0) {                                                 // a new tap (scalar branch, every C / 64 K tiles): this half's source offsets
         const int r = (tap * 11) >> 5, s_ = tap - 3 * r;
         const int d_r = p.transposed ? 1 - r : r - 1, d_s = p.transposed ? 1 - s_ : s_ - 1;
         const int dpix = (d_r * p.W + d_s) * p.C * 2;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int k = which * 2 + h, ih = (ohw[k] >> 16) + d_r, iw = (ohw[k] & 0xffff) + d_s;
+        for (int h = 0; h < nk; ++h) {
+          const int k = k0 + h, ih = (ohw[k] >> 16) + d_r, iw = (ohw[k] & 0xffff) + d_s;
           voffA[k] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? pixb[k] + dpix : OOB_G8;
         }
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-        dma16_g8(rsX, base + (unsigned)((2 * w + h) * 1024), okt ? voffA[which * 2 + h] : OOB_G8, okt ? cc * 128 : 0);
+      for (int h = 0; h < nk; ++h)
+        dma16_g8(rsX, base + (unsigned)((w * nk + h) * 1024), okt ? voffA[k0 + h] : OOB_G8, okt ? cc * 128 : 0);   // (scalar offset: wave-uniform)
     } else {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int pc = 2 * w + h, row = g8_row_of(which, pc * 8);
-        dma16_g8(rsW, base + (unsigned)(pc * 1024), okt ? voffB : OOB_G8, okt ? ((n0 + row) * p.K + t * G8_BK) * 2 : 0);
+      for (int h = 0; h < G::N_B; ++h) {
+        const int pc = w * G::N_B + h, r0 = pc * 8;                  // buffer rows: 32 of the 64 columns of each N group
+        const bool okp = okt && r0 < G::B_ROWS;
+        const int col = (r0 / 32) * 64 + (r0 % 32) + (which == 3 ? 32 : 0);
+        dma16_g8(rsW, base + (unsigned)(pc * 1024), okp ? voffB : OOB_G8, okp ? ((n0 + col) * p.K + t * G8_BK) * 2 : 0);
       }
     }
   };
 
   const int fl = ((li >> 2) & 1) << 1;
-  const unsigned ra0 = (unsigned)((wr * 64 + li) * 128 + ((g ^ fl) << 4));     // A first:  + i * 2048 + kk * 64, i < 4
-  const unsigned ra1 = (unsigned)((wr * 48 + li) * 128 + ((g ^ fl) << 4));     // A second: i < 3
-  const unsigned rb = (unsigned)((wc * 32 + li) * 128 + ((g ^ fl) << 4));
+  const unsigned ra0 = (unsigned)(G::OFF_AF + (wm * 64 + li) * 128 + ((g ^ fl) << 4));     // + i * 2048 + kk * 64, i < 4
+  const unsigned ra1 = (unsigned)(G::OFF_AS + (wm * 48 + li) * 128 + ((g ^ fl) << 4));     // i < 3
+  const unsigned rb0 = (unsigned)(G::OFF_BF + (wn * 32 + li) * 128 + ((g ^ fl) << 4));
+  const unsigned rb1 = (unsigned)(G::OFF_BS + (wn * 32 + li) * 128 + ((g ^ fl) << 4));
 
   f32x4 acc[7][4];
 #pragma unroll
@@ -285,11 +312,13 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 a0[4][2], a1[3][2], b0[2][2], b1[2][2];
 
-#define C8_RD(dst, which, off) dst = *reinterpret_cast<const bf16x8*>(smem + (d * 4 + (which)) * G8_HALF + (off))
+#define C8_RD(dst, off) dst = *reinterpret_cast<const bf16x8*>(smem + d * G::BUF + (off))
+#define C8_WAIT() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::INFLIGHT) : "memory")
+
   stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(2, 1);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  C8_WAIT();                                                        // A first (0), B first (0) landed (this wave's pieces)
   G8_BAR();
-  if (wr == 1) G8_BAR();
+  if (grp == 1) G8_BAR();                                           // group 1 runs one barrier behind group 0 from here on
 
   for (int t = 0; t < nkt; ++t) {
     const int d = t & 1;
@@ -297,14 +326,14 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) C8_RD(b0[j][kk], 2, rb + j * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) C8_RD(b0[j][kk], rb0 + j * 2048 + kk * 64);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) C8_RD(a0[i][kk], 0, ra0 + i * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) C8_RD(a0[i][kk], ra0 + i * 2048 + kk * 64);
     stage(3, t + 1);
-    G8_WAIT();
+    C8_WAIT();
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     G8_COMPUTE(a0, b0, 0, 0, 4);
@@ -313,9 +342,9 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) C8_RD(b1[j][kk], 3, rb + j * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) C8_RD(b1[j][kk], rb1 + j * 2048 + kk * 64);
     stage(1, t + 1);
-    G8_WAIT();
+    C8_WAIT();
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     G8_COMPUTE(a0, b1, 0, 2, 4);
@@ -324,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) C8_RD(a1[i][kk], 1, ra1 + i * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) C8_RD(a1[i][kk], ra1 + i * 2048 + kk * 64);
     stage(0, t + 2);
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -332,17 +361,18 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     G8_BAR();
     // ---------------- P4: rows 64-111 x columns 0-31
     stage(2, t + 2);
-    G8_WAIT();
+    C8_WAIT();
     G8_BAR();
     G8_COMPUTE(a1, b0, 4, 0, 3);
     G8_BAR();
   }
-  if (wr == 0) G8_BAR();
+  if (grp == 0) G8_BAR();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the out-of-range tail pieces have written their zeros
   G8_BAR();
 #undef C8_RD
+#undef C8_WAIT
 
-  // ---- epilogue 1: bf16 tile -> LDS  (acc[mi][nj][r] = out[row 112 wr + 16 mi + li][column 64 wc + 16 nj + 4 g + r])
+  // ---- epilogue 1: bf16 tile -> LDS  (acc[mi][nj][r] = out[row 112 wm + 16 mi + li][column 64 wn + 16 nj + 4 g + r])
   typedef __attribute__((ext_vector_type(2))) float f32x2_t;
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
@@ -353,19 +383,19 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
       u32x2_t o;
       o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[mi][nj][0], acc[mi][nj][1]}, bf16x2_t));
       o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[mi][nj][2], acc[mi][nj][3]}, bf16x2_t));
-      *reinterpret_cast<u32x2_t*>(smem + (wr * 112 + mi * 16 + li) * C8_LDC + (wc * 64 + nj * 16 + 4 * g) * 2) = o;
+      *reinterpret_cast<u32x2_t*>(smem + (wm * 112 + mi * 16 + li) * G::LDC + (wn * 64 + nj * 16 + 4 * g) * 2) = o;
     }
   __syncthreads();
-  // ---- epilogue 2: full 512-byte row segments out; column sums of the stored (bf16) values
-  const int c16 = tid & 31, rg = tid >> 5;
+  // ---- epilogue 2: full row segments out; column sums of the stored (bf16) values
+  const int c16 = tid % G::CPR, rg = tid / G::CPR;
   float cs[8], cq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
   const int rows = min(p.rpt, p.M - m0);
   const bool fused = p.addend != nullptr || p.outmask != nullptr;
   if (!fused) {
-    for (int R = rg; R < rows; R += 16) {
-      Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + R * C8_LDC + c16 * 16);
+    for (int R = rg; R < rows; R += G::RG) {
+      Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + R * G::LDC + c16 * 16);
       *reinterpret_cast<u32x4*>(p.out + (size_t)(m0 + R) * p.N + n0 + c16 * 8) = v.raw;
       if (p.stats) {
 #pragma unroll
@@ -375,13 +405,13 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   } else {
     // out = (conv + addend * (addmask > 0)) * (outmask > 0) on the staged bf16 value, like igemm_kernel's epilogue (the identity-path
     // gradient and the ReLU masks of the data gradients, engine._block_bwd); two rows per step, every load ahead of the first store
-    for (int R = rg; R < rows; R += 32) {
+    for (int R = rg; R < rows; R += 2 * G::RG) {
       Vec16<bf16_t> av[2], mv[2], ov[2];
       bool live[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        live[i] = R + 16 * i < rows;
-        const size_t off = (size_t)(m0 + R + 16 * i) * p.N + n0 + c16 * 8;
+        live[i] = R + G::RG * i < rows;
+        const size_t off = (size_t)(m0 + R + G::RG * i) * p.N + n0 + c16 * 8;
         if (live[i]) {
           if (p.addend) av[i] = ldg16(p.addend + off);
           if (p.addend && p.addmask) mv[i] = ldg16(p.addmask + off);
@@ -391,8 +421,8 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (!live[i]) continue;
-        const size_t off = (size_t)(m0 + R + 16 * i) * p.N + n0 + c16 * 8;
-        Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + (R + 16 * i) * C8_LDC + c16 * 16);
+        const size_t off = (size_t)(m0 + R + G::RG * i) * p.N + n0 + c16 * 8;
+        Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + (R + G::RG * i) * G::LDC + c16 * 16);
         if (p.addend) {
           if (p.addmask) {
 #pragma unroll
@@ -416,16 +446,18 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   }
   if (p.stats) {
     __syncthreads();                                                // the staged tile has been read: its LDS is reused for the partial sums
-    float* part = reinterpret_cast<float*>(smem);                   // [16 row groups][2][256]
+    float* part = reinterpret_cast<float*>(smem);                   // [RG row groups][2][BN]
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { part[(rg * 2 + 0) * 256 + c16 * 8 + j] = cs[j]; part[(rg * 2 + 1) * 256 + c16 * 8 + j] = cq[j]; }
+    for (int j = 0; j < 8; ++j) { part[(rg * 2 + 0) * G::BN + c16 * 8 + j] = cs[j]; part[(rg * 2 + 1) * G::BN + c16 * 8 + j] = cq[j]; }
     __syncthreads();
-    const int k = tid >> 8, c = tid & 255;                          // 512 threads = 2 sums x 256 columns
-    float t = 0.f;
+    if (tid < 2 * G::BN) {
+      const int k = tid / G::BN, c = tid - k * G::BN;
+      float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t += part[(q * 2 + k) * 256 + c];
-    const int Rr = acc_replicas(p.N);
-    acc_add_fixed(p.stats, (size_t)Rr * 2 * p.N, (size_t)(tm % Rr) * 2 * p.N + (size_t)k * p.N + n0 + c, t);
+      for (int q = 0; q < G::RG; ++q) t += part[(q * 2 + k) * G::BN + c];
+      const int Rr = acc_replicas(p.N);
+      acc_add_fixed(p.stats, (size_t)Rr * 2 * p.N, (size_t)(tm % Rr) * 2 * p.N + (size_t)k * p.N + n0 + c, t);
+    }
   }
 }
 
@@ -444,17 +476,19 @@ int vqa_gemm8p(const void* A, const void* B, void* C, int M, int N, int K, hipSt
   hipLaunchKernelGGL(gemm8p_kernel, dim3(p.ntiles), dim3(512), G8_LDS, st, p);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
-// 1: vqa_conv8p takes the shape (3x3 / stride 1 / pad 1, NHWC bf16, C a power-of-two multiple of 64, N a multiple of 256)
+// 1: vqa_conv8p takes the shape (3x3 / stride 1 / pad 1, NHWC bf16, C a power-of-two multiple of 64, N a multiple of 128)
 int vqa_conv8p_ok(int B, int H, int W, int C, int N) {
-  if (B <= 0 || H <= 0 || W <= 0 || H > 16383 || W > 16383 || C < 64 || (C & (C - 1)) || N <= 0 || N % G8_BN) return 0;
-  const size_t xb = (size_t)B * H * W * C * 2, wb = (size_t)N * 9 * C * 2;
-  if (xb >= 0x7fffffffull || wb >= 0x7fffffffull || (size_t)B * H * W >= 0x7fffffffull / 2) return 0;
+  if (B <= 0 || H <= 0 || W <= 0 || H > 16383 || W > 16383 || C < 64 || (C & (C - 1)) || N <= 0 || N % 128) return 0;
+  const size_t xb = (size_t)B * H * W * C * 2, wb = (size_t)N * 9 * C * 2, ob = (size_t)B * H * W * N * 2;
+  if (xb >= 0x7fffffffull || wb >= 0x7fffffffull || (size_t)B * H * W >= 0x7fffffffull / 2 || ob >= 0xffffffffull * 2) return 0;
   return 1;
 }
 // out[B*H*W][N] = conv3x3(x [B][H][W][C], w [N][(r, s, c)]) (transposed = 0), or the stride-1 data gradient (transposed = 1: x is dy
 // [B][H][W][Cout], w the packed [Cin][(tap, Cout)] operand of vqa_pack_transpose, taps mirrored).  stats: fixed-point BatchNorm
 // accumulator (vqa_bn_acc_words(2, N), caller-zeroed) receiving sum y | sum y^2 of the stored values, or NULL.
 // addend / addmask / outmask [B*H*W][N] bf16 or NULL: out = (conv + addend * (addmask > 0)) * (outmask > 0), the epilogue of vqa_igemm.
+// Tile: 224 x 256 (2 x 4 waves) when 256 divides N, else 448 x 128 (4 x 2 waves); 7/8 of the rows valid (196 / 392) when that divides
+// B*H*W -- the 14 x 14, 7 x 7 and 28 x 28 maps of the model: exactly 2, 1 and 4 rounds of 256 CUs at B = 512.
 int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stats, const void* addend, const void* addmask, const void* outmask,
                int B, int H, int W, int C, int N, int transposed, hipStream_t st) {
   if (!x || !w || !out || !vqa_conv8p_ok(B, H, W, C, N)) return VQA_EARG;
@@ -464,17 +498,24 @@ int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stat
   p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.outmask = (const bf16_t*)outmask;
   p.M = B * H * W; p.N = N; p.K = 9 * C; p.B = B; p.H = H; p.W = W; p.C = C; p.transposed = transposed;
   p.x_bytes = (unsigned)((size_t)B * H * W * C * 2); p.w_bytes = (unsigned)((size_t)N * 9 * C * 2);
-  // valid rows per 224-row tile: 196 (= one 14 x 14 image / four 7 x 7 images: 512 / 256 tiles at B = 512) when that divides M, else all 224
-  p.rpt = (p.M % 196 == 0) ? 196 : C8_BMP;
-  p.tiles_n = N / G8_BN;
+  const bool wide = N % 256 == 0;
+  const int bmp = wide ? 224 : 448;
+  p.rpt = (p.M % (bmp / 8 * 7) == 0) ? bmp / 8 * 7 : bmp;
+  p.tiles_n = N / (wide ? 256 : 128);
   const int tiles_m = (p.M + p.rpt - 1) / p.rpt;
   if (stats && tiles_m > VQA_ACC_MAX_PARTS) return VQA_EARG;
   p.ntiles = tiles_m * p.tiles_n;
   p.cpk_shift = 0;
   while ((64 << p.cpk_shift) < C) ++p.cpk_shift;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS); attr = true; }
-  hipLaunchKernelGGL(conv8p_kernel, dim3(p.ntiles), dim3(512), G8_LDS, st, p);
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C8Geo<2, 4>::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C8Geo<4, 2>::LDS);
+    attr = true;
+  }
+  constexpr int lds_w = C8Geo<2, 4>::LDS, lds_n = C8Geo<4, 2>::LDS;
+  if (wide) hipLaunchKernelGGL((conv8p_kernel<2, 4>), dim3(p.ntiles), dim3(512), lds_w, st, p);
+  else hipLaunchKernelGGL((conv8p_kernel<4, 2>), dim3(p.ntiles), dim3(512), lds_n, st, p);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 }

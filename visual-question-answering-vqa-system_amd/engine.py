@@ -282,8 +282,11 @@ class HipEngine:
                 and self.use_c64p)
 
     def _c8p_ok(self, B, H, W, Cin, Cout, R, stride, pad):
-        """3x3 / 1 / pad 1 conv (or stride-1 data gradient) the 8-phase tile takes: bf16, channels a power-of-two multiple of 64, >= 256 outputs."""
-        return (self.use_conv8p and self.dtype == torch.bfloat16 and R == 3 and stride == 1 and pad == 1 and K.conv8p_ok(B, H, W, Cin, Cout))
+        """3x3 / 1 / pad 1 conv (or stride-1 data gradient) routed to the 8-phase 224 x 256 tile: bf16, output channels a multiple of 256 (stages
+        3 and 4).  The 448 x 128 form of the kernel (N = 128: stage 2) is parity-tested but NOT routed: 167 / 150 us against 168 / 140 us for
+        the 128 x 128 window-loader tile at B = 512 (K = 1152 is only 18 K tiles; profiles/r04_gemm8p_bench.txt)."""
+        return (self.use_conv8p and self.dtype == torch.bfloat16 and R == 3 and stride == 1 and pad == 1 and Cout % 256 == 0
+                and K.conv8p_ok(B, H, W, Cin, Cout))
 
     def _wflip(self, name):                  # [Cin][(2-r,2-s)][Cout] operand of the stride-1 data gradient as a plain 3x3 conv
         e = self.E[name]
