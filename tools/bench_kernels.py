@@ -55,6 +55,17 @@ for name, Cin, Cout, H, R, stride, pad in CONVS:
     t = timeit(lambda: K.wgrad(dy, x, dw, M, Cout, Kw, geom, dtype=T), args.iters)
     print(f"{name:22s} wgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
 
+if not args.only or "c8p" in args.only:
+    for name, C, H in (("s3 256->256 14", 256, 14), ("s4 512->512 7", 512, 7)):
+        x = torch.randn(B * H * H, C, device=dev).to(T)
+        w = (torch.randn(C, 9 * C, device=dev) * 0.03).to(T)
+        fl = 2.0 * B * H * H * C * 9 * C
+        words = K.L.count("vqa_bn_acc_words", 2, C)
+        t = timeit(lambda: K.conv8p(x, w, B, H, H, C, C, stats_acc=torch.zeros(words, device=dev, dtype=torch.int64)), args.iters)
+        print(f"{name:22s} conv8p fwd   {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
+        t = timeit(lambda: K.conv8p(x, w, B, H, H, C, C, transposed=1), args.iters)
+        print(f"{name:22s} conv8p dgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
+
 if not args.only or "c64" in args.only:
     H = 56
     x = torch.randn(B * H * H, 64, device=dev).to(T)

@@ -21,7 +21,7 @@ def load(d):
 a, b = load(sys.argv[1]), load(sys.argv[2])
 out = {}
 for k in a:
-    if not any(t in k for t in ("igemm_kernel", "wgrad_kernel", "wgrad3x3_c64", "stem_wgrad")) or k not in b:
+    if not any(t in k for t in ("igemm_kernel", "wgrad_kernel", "wgrad3x3_c", "stem_wgrad", "conv8p_kernel", "conv3x3_c64p", "wgrad_dma_kernel")) or k not in b:
         continue
     c, d = a[k], b[k]
     cyc = c["SQ_BUSY_CYCLES"] / 32.0

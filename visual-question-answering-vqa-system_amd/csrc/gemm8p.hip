@@ -10,8 +10,11 @@
 //   * a K tile (64) is consumed in 4 phases (quadrants 00, 01, 11, 10); operands arrive as four 16 KB half-tiles per K tile
 //     (A rows needed first / second, B columns needed first / second), ONE half-tile staged per phase by LDS-DMA into a double
 //     buffer (8 x 16 KB = 128 KB), four half-tiles in flight, counted vmcnt waits, raw s_barrier (never vmcnt(0) in the loop);
-//   * LDS rows are 128 bytes, XOR-swizzled on the DMA source side (16-byte slot bit 1 ^= row bit 2) so a ds_read_b128 fragment
-//     read is 4-way instead of 8-way conflicted.
+//   * LDS rows are 128 bytes, XOR-swizzled on the DMA source side: the 16-byte slot index (3 bits) ^= (row >> 1) & 7.  A ds_read_b128
+//     is served in four groups of 16 lanes ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) over a 256-byte bank window = two rows;
+//     with this map the 16 lanes of every group hit 16 different slots of the window: conflict-free fragment reads.  (Measured against the
+//     guide's st_16x32 swizzle -- slot bit 1 ^= row bit 2, 4-way conflicted by the same table: 1193 / 1307 vs 1220 / 1291 TFLOP/s at
+//     4096^3 / 8192^3, i.e. NEUTRAL: the fragment reads are not what bounds this schedule.  Kept: it costs two address registers.)
 // Hazard bookkeeping (phase p of K tile t = global phase 4t + p; group 1 = waves 4-7 runs one barrier behind group 0):
 //   staged in phase | half-tile      | its buffer was last read in | first read in
 //   P1(t)           | B second (t+1) | P2(t-1)                     | P2(t+1)   (waited for in P1(t+1))
@@ -72,9 +75,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
   const i32x4_g8 rsB = {(int)(unsigned)ba, (int)((unsigned)(ba >> 32) & 0xffffu), (int)p.b_bytes, 0x00020000};
 
   // ---- DMA plan: a piece = 8 buffer rows x 128 bytes; wave w stages pieces 2w, 2w+1 of every half-tile.  Lane: row dr of the piece,
-  //      LDS slot dc; the SOURCE chunk is dc ^ f(row), f = ((row >> 2) & 1) << 1 (the swizzle lives on the source side).
+  //      LDS slot dc; the SOURCE chunk is dc ^ f(row), f = (row >> 1) & 7 = (dr >> 1) | (piece parity << 2) (the swizzle lives on the source side).
   const int dr = lane >> 3, dc = lane & 7;
-  const int voff = dr * p.K * 2 + ((dc ^ (((dr >> 2) & 1) << 1)) << 4);
+  const int voff0 = dr * p.K * 2 + ((dc ^ (dr >> 1)) << 4), voff1 = dr * p.K * 2 + ((dc ^ (dr >> 1) ^ 4) << 4);   // even / odd piece (row bit 3)
   const int nkt = p.K / G8_BK;
   auto stage = [&](int which, int t) {             // half-tile `which` of K tile t into buffer t & 1 (t >= nkt: out of range -> zeros)
     const unsigned base = lds0 + (unsigned)(((t & 1) * 4 + which) * G8_HALF);
@@ -83,14 +86,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
     for (int h = 0; h < 2; ++h) {
       const int pc = 2 * w + h, row = g8_row_of(which, pc * 8);
       const int so = ((which < 2 ? m0 : n0) + row) * p.K * 2 + t * (G8_BK * 2);
-      dma16_g8(which < 2 ? rsA : rsB, base + (unsigned)(pc * 1024), ok ? voff : OOB_G8, ok ? so : 0);
+      dma16_g8(which < 2 ? rsA : rsB, base + (unsigned)(pc * 1024), ok ? (h ? voff1 : voff0) : OOB_G8, ok ? so : 0);
     }
   };
 
   // ---- fragment read addresses (bytes, relative to a half-tile buffer): row = (wave's first row) + 16 i + li, slot = (4 kk + g) ^ f
-  const int fl = ((li >> 2) & 1) << 1;
-  const unsigned ra = (unsigned)((wr * 64 + li) * 128 + ((g ^ fl) << 4));      // + i * 2048 + kk * 64
-  const unsigned rb = (unsigned)((wc * 32 + li) * 128 + ((g ^ fl) << 4));      // + j * 2048 + kk * 64
+  const int fl = (li >> 1) & 7;
+  const unsigned sk[2] = {(unsigned)((g ^ fl) << 4), (unsigned)((g ^ fl ^ 4) << 4)};       // slot of k half kk (the XOR may flip bit 2: not an immediate)
+  const unsigned ra = (unsigned)((wr * 64 + li) * 128);      // + i * 2048 + sk[kk]
+  const unsigned rb = (unsigned)((wc * 32 + li) * 128);      // + j * 2048 + sk[kk]
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -126,12 +130,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) G8_RD(b0[j][kk], 2, rb + j * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) G8_RD(b0[j][kk], 2, rb + j * 2048 + sk[kk]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) G8_RD(a0[i][kk], 0, ra + i * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) G8_RD(a0[i][kk], 0, ra + i * 2048 + sk[kk]);
     stage(3, t + 1);
     G8_WAIT();                                                      // B second (t) landed -> read in P2
     G8_BAR();
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) G8_RD(b1[j][kk], 3, rb + j * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) G8_RD(b1[j][kk], 3, rb + j * 2048 + sk[kk]);
     stage(1, t + 1);
     G8_WAIT();                                                      // A second (t) landed -> read in P3
     G8_BAR();
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) G8_RD(a1[i][kk], 1, ra + i * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) G8_RD(a1[i][kk], 1, ra + i * 2048 + sk[kk]);
     stage(0, t + 2);
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -247,7 +251,8 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   const i32x4_g8 rsX = {(int)(unsigned)xa, (int)((unsigned)(xa >> 32) & 0xffffu), (int)p.x_bytes, 0x00020000};
   const i32x4_g8 rsW = {(int)(unsigned)wa, (int)((unsigned)(wa >> 32) & 0xffffu), (int)p.w_bytes, 0x00020000};
   const int nkt = p.K / G8_BK;
-  const int dr = lane >> 3, dc = lane & 7, slot = (dc ^ (((dr >> 2) & 1) << 1)) << 4;
+  const int dr = lane >> 3, dc = lane & 7;
+  const int slot_e = (dc ^ (dr >> 1)) << 4, slot_o = (dc ^ (dr >> 1) ^ 4) << 4;       // source slot of an even / odd piece (LDS row bit 3)
   const int HW = p.H * p.W;
 
   // ---- this lane's staged A rows: piece pc = w * N + h of A first (h < N_AF) and A second (h < N_AS); decoded once
@@ -256,7 +261,8 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
   for (int k = 0; k < NA; ++k) {
     const bool second = k >= G::N_AF;
-    const int r = ((second ? w * G::N_AS + (k - G::N_AF) : w * G::N_AF + k)) * 8 + dr;      // buffer row
+    const int pck = second ? w * G::N_AS + (k - G::N_AF) : w * G::N_AF + k;                 // piece
+    const int r = pck * 8 + dr, slot = (pck & 1) ? slot_o : slot_e;                         // buffer row
     int R;
     if (!second) R = (r / 64) * 112 + (r % 64);                                             // first 64 rows of each M group
     else R = r < G::AS_ROWS ? (r / 48) * 112 + 64 + (r % 48) : G::BMP;                      // the other 48 (pieces beyond: none)
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
       ohw[k] = (oh << 16) | ow;
     } else { pixb[k] = 0; ohw[k] = (int)0xc0000000; }                // oh = -16384: every tap fails the range test
   }
-  const int voffB = dr * p.K * 2 + slot;
+  const int voffB0 = dr * p.K * 2 + slot_e, voffB1 = dr * p.K * 2 + slot_o;
   auto stage = [&](int which, int t) {                               // which: 0 A first, 1 A second, 2 B first, 3 B second
     const unsigned base = lds0 + (unsigned)((t & 1) * G::BUF + (which == 0 ? G::OFF_AF : which == 1 ? G::OFF_AS : which == 2 ? G::OFF_BF : G::OFF_BS));
     const bool okt = t < nkt;
@@ -294,16 +300,17 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
         const int pc = w * G::N_B + h, r0 = pc * 8;                  // buffer rows: 32 of the 64 columns of each N group
         const bool okp = okt && r0 < G::B_ROWS;
         const int col = (r0 / 32) * 64 + (r0 % 32) + (which == 3 ? 32 : 0);
-        dma16_g8(rsW, base + (unsigned)(pc * 1024), okp ? voffB : OOB_G8, okp ? ((n0 + col) * p.K + t * G8_BK) * 2 : 0);
+        dma16_g8(rsW, base + (unsigned)(pc * 1024), okp ? ((pc & 1) ? voffB1 : voffB0) : OOB_G8, okp ? ((n0 + col) * p.K + t * G8_BK) * 2 : 0);
       }
     }
   };
 
-  const int fl = ((li >> 2) & 1) << 1;
-  const unsigned ra0 = (unsigned)(G::OFF_AF + (wm * 64 + li) * 128 + ((g ^ fl) << 4));     // + i * 2048 + kk * 64, i < 4
-  const unsigned ra1 = (unsigned)(G::OFF_AS + (wm * 48 + li) * 128 + ((g ^ fl) << 4));     // i < 3
-  const unsigned rb0 = (unsigned)(G::OFF_BF + (wn * 32 + li) * 128 + ((g ^ fl) << 4));
-  const unsigned rb1 = (unsigned)(G::OFF_BS + (wn * 32 + li) * 128 + ((g ^ fl) << 4));
+  const int fl = (li >> 1) & 7;
+  const unsigned sk[2] = {(unsigned)((g ^ fl) << 4), (unsigned)((g ^ fl ^ 4) << 4)};       // slot of k half kk
+  const unsigned ra0 = (unsigned)(G::OFF_AF + (wm * 64 + li) * 128);     // + i * 2048 + sk[kk], i < 4
+  const unsigned ra1 = (unsigned)(G::OFF_AS + (wm * 48 + li) * 128);     // i < 3
+  const unsigned rb0 = (unsigned)(G::OFF_BF + (wn * 32 + li) * 128);
+  const unsigned rb1 = (unsigned)(G::OFF_BS + (wn * 32 + li) * 128);
 
   f32x4 acc[7][4];
 #pragma unroll
@@ -326,12 +333,12 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) C8_RD(b0[j][kk], rb0 + j * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) C8_RD(b0[j][kk], rb0 + j * 2048 + sk[kk]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) C8_RD(a0[i][kk], ra0 + i * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) C8_RD(a0[i][kk], ra0 + i * 2048 + sk[kk]);
     stage(3, t + 1);
     C8_WAIT();
     G8_BAR();
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) C8_RD(b1[j][kk], rb1 + j * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) C8_RD(b1[j][kk], rb1 + j * 2048 + sk[kk]);
     stage(1, t + 1);
     C8_WAIT();
     G8_BAR();
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) C8_RD(a1[i][kk], ra1 + i * 2048 + kk * 64);
+      for (int kk = 0; kk < 2; ++kk) C8_RD(a1[i][kk], ra1 + i * 2048 + sk[kk]);
     stage(0, t + 2);
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
