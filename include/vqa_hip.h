@@ -76,7 +76,7 @@ int vqa_gemm8p(const void* A, const void* B, void* C, int M, int N, int K, hipSt
 int vqa_conv8p_ok(int B, int H, int W, int C, int N);
 int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stats,
                const void* addend, const void* addmask, const void* outmask /* [B*H*W][N] bf16 or NULL: out = (conv + addend * (addmask > 0)) * (outmask > 0) */,
-               int B, int H, int W, int C, int N, int transposed, hipStream_t stream);
+               int B, int H, int W, int C, int N, int transposed, int stride /* 1, or 2: forward 3x3 / 2 convs (H, W = input map) */, hipStream_t stream);
 /* Round 4 -- training-mode "Conv3x3 + BN + ReLU" without the normalised tensor (models/cnn_backbone.py:182-187: conv1 -> bn1 -> relu ->
  * conv2 at 64 channels).  vqa_conv3x3_c64p_bn is vqa_conv3x3_c64p applied to relu(BatchNorm(y)): y = the previous conv's raw output,
  * acc = its fixed-point statistics (the launch that wrote y ran with stats_mode = 1).  Every workgroup finalizes the 64 coefficients in

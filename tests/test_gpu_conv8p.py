@@ -28,6 +28,26 @@ def test_gemm8p_matches_matmul(M, N, K):
         L.call("vqa_gemm8p", A.data_ptr(), B.data_ptr(), C.data_ptr(), M + 1, N, K)
 
 
+@pytest.mark.parametrize("B,H,W,C,N", [(4, 28, 28, 128, 256), (8, 14, 14, 256, 512), (3, 9, 11, 64, 256)])
+def test_conv8p_stride2_forward_matches_aten(B, H, W, C, N):
+    """The stage-entry 3x3 / 2 / pad 1 convs (models/cnn_backbone.py:243-247 main branch) on the same tile: gathered input pixels oh*2 + r - 1."""
+    K, L = sub("kernels"), sub("_lib")
+    g = torch.Generator().manual_seed(B + H + C + N)
+    x = torch.randn(B * H * W, C, generator=g).to(DEV, bf)
+    wq = (torch.randn(N, 3, 3, C, generator=g) * 0.05).to(DEV, bf)
+    acc = torch.zeros(L.count("vqa_bn_acc_words", 2, N), device=DEV, dtype=torch.int64)
+    out = K.conv8p(x, wq.view(N, 9 * C), B, H, W, C, N, stride=2, stats_acc=acc)
+    torch.cuda.synchronize()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    ref = F.conv2d(x.float().view(B, H, W, C).permute(0, 3, 1, 2).cpu(), wq.float().permute(0, 3, 1, 2).cpu(), stride=2, padding=1)
+    got = out.float().view(B, Ho, Wo, N).permute(0, 3, 1, 2).cpu()
+    assert ref.shape == got.shape and (got - ref).abs().max().item() <= 6e-3 * max(1.0, ref.abs().max().item())
+    sums, flag = _acc_decode(acc, max(1, min(8, 512 // N)), 2, N)
+    assert flag == 0 and (sums[0] - out.double().sum(0)).abs().max().item() <= 1e-3 * max(1.0, float(out.double().sum(0).abs().max()))
+    with pytest.raises(RuntimeError):
+        K.conv8p(x, wq.view(N, 9 * C), B, H, W, C, N, stride=2, transposed=1)
+
+
 def _acc_decode(acc, R, K, C):
     n = R * K * C
     return (acc[:n].view(R, K, C).sum(0).double() / 16.0 + acc[n + 1: 2 * n + 1].view(R, K, C).sum(0).double() / float(1 << 50)), int(acc[n])

@@ -210,6 +210,7 @@ struct C8Params {
   const bf16_t* x; const bf16_t* w; bf16_t* out; unsigned long long* stats;
   const bf16_t* addend; const bf16_t* addmask; const bf16_t* outmask;   // epilogue inputs [M][N] or NULL (as vqa_igemm)
   int M, N, K, B, H, W, C, transposed, rpt, tiles_n, ntiles, cpk_shift;
+  int Ho, Wo, stride;                 // output map (= H, W for stride 1); forward convs also run with stride 2 (the stage-entry 3x3 / 2 convs)
   unsigned x_bytes, w_bytes;
 };
 
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   const int nkt = p.K / G8_BK;
   const int dr = lane >> 3, dc = lane & 7;
   const int slot_e = (dc ^ (dr >> 1)) << 4, slot_o = (dc ^ (dr >> 1) ^ 4) << 4;       // source slot of an even / odd piece (LDS row bit 3)
-  const int HW = p.H * p.W;
+  const int HW = p.Ho * p.Wo;
 
   // ---- this lane's staged A rows: piece pc = w * N + h of A first (h < N_AF) and A second (h < N_AS); decoded once
   constexpr int NA = G::N_AF + G::N_AS;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     const int m = m0 + R;
     voffA[k] = OOB_G8;
     if (R < p.rpt && m < p.M) {
-      const int b = m / HW, rem = m - b * HW, oh = rem / p.W, ow = rem - oh * p.W;
+      const int b = m / HW, rem = m - b * HW, oh = (rem / p.Wo) * p.stride, ow = (rem - (rem / p.Wo) * p.Wo) * p.stride;   // input pixel of tap (1, 1)
       pixb[k] = ((b * p.H + oh) * p.W + ow) * p.C * 2 + slot;
       ohw[k] = (oh << 16) | ow;
     } else { pixb[k] = 0; ohw[k] = (int)0xc0000000; }                // oh = -16384: every tap fails the range test
@@ -484,7 +485,7 @@ int vqa_gemm8p(const void* A, const void* B, void* C, int M, int N, int K, hipSt
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 // 1: vqa_conv8p takes the shape (3x3 / stride 1 / pad 1, NHWC bf16, C a power-of-two multiple of 64, N a multiple of 128)
-int vqa_conv8p_ok(int B, int H, int W, int C, int N) {
+int vqa_conv8p_ok(int B, int H, int W, int C, int N) {      // (H, W: the INPUT map)
   if (B <= 0 || H <= 0 || W <= 0 || H > 16383 || W > 16383 || C < 64 || (C & (C - 1)) || N <= 0 || N % 128) return 0;
   const size_t xb = (size_t)B * H * W * C * 2, wb = (size_t)N * 9 * C * 2, ob = (size_t)B * H * W * N * 2;
   if (xb >= 0x7fffffffull || wb >= 0x7fffffffull || (size_t)B * H * W >= 0x7fffffffull / 2 || ob >= 0xffffffffull * 2) return 0;
@@ -494,16 +495,18 @@ int vqa_conv8p_ok(int B, int H, int W, int C, int N) {
 // [B][H][W][Cout], w the packed [Cin][(tap, Cout)] operand of vqa_pack_transpose, taps mirrored).  stats: fixed-point BatchNorm
 // accumulator (vqa_bn_acc_words(2, N), caller-zeroed) receiving sum y | sum y^2 of the stored values, or NULL.
 // addend / addmask / outmask [B*H*W][N] bf16 or NULL: out = (conv + addend * (addmask > 0)) * (outmask > 0), the epilogue of vqa_igemm.
+// stride: 1, or 2 (forward only: the 3x3 / 2 / pad 1 stage-entry convs; out is [B][(H+1)/2... ][N], i.e. Ho = (H - 1) / 2 + 1).
 // Tile: 224 x 256 (2 x 4 waves) when 256 divides N, else 448 x 128 (4 x 2 waves); 7/8 of the rows valid (196 / 392) when that divides
 // B*H*W -- the 14 x 14, 7 x 7 and 28 x 28 maps of the model: exactly 2, 1 and 4 rounds of 256 CUs at B = 512.
 int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stats, const void* addend, const void* addmask, const void* outmask,
-               int B, int H, int W, int C, int N, int transposed, hipStream_t st) {
-  if (!x || !w || !out || !vqa_conv8p_ok(B, H, W, C, N)) return VQA_EARG;
+               int B, int H, int W, int C, int N, int transposed, int stride, hipStream_t st) {
+  if (!x || !w || !out || !vqa_conv8p_ok(B, H, W, C, N) || (stride != 1 && stride != 2) || (stride == 2 && transposed)) return VQA_EARG;
   C8Params p;
   if (addmask && !addend) return VQA_EARG;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
   p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.outmask = (const bf16_t*)outmask;
-  p.M = B * H * W; p.N = N; p.K = 9 * C; p.B = B; p.H = H; p.W = W; p.C = C; p.transposed = transposed;
+  p.stride = stride; p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (W + 2 - 3) / stride + 1;
+  p.M = B * p.Ho * p.Wo; p.N = N; p.K = 9 * C; p.B = B; p.H = H; p.W = W; p.C = C; p.transposed = transposed;
   p.x_bytes = (unsigned)((size_t)B * H * W * C * 2); p.w_bytes = (unsigned)((size_t)N * 9 * C * 2);
   const bool wide = N % 256 == 0;
   const int bmp = wide ? 224 : 448;

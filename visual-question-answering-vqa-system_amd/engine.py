@@ -285,7 +285,7 @@ class HipEngine:
         """3x3 / 1 / pad 1 conv (or stride-1 data gradient) routed to the 8-phase 224 x 256 tile: bf16, output channels a multiple of 256 (stages
         3 and 4).  The 448 x 128 form of the kernel (N = 128: stage 2) is parity-tested but NOT routed: 167 / 150 us against 168 / 140 us for
         the 128 x 128 window-loader tile at B = 512 (K = 1152 is only 18 K tiles; profiles/r04_gemm8p_bench.txt)."""
-        return (self.use_conv8p and self.dtype == torch.bfloat16 and R == 3 and stride == 1 and pad == 1 and Cout % 256 == 0
+        return (self.use_conv8p and self.dtype == torch.bfloat16 and R == 3 and stride in (1, 2) and pad == 1 and Cout % 256 == 0
                 and K.conv8p_ok(B, H, W, Cin, Cout))
 
     def _wflip(self, name):                  # [Cin][(2-r,2-s)][Cout] operand of the stride-1 data gradient as a plain 3x3 conv
@@ -308,7 +308,7 @@ class HipEngine:
             return y, st, mt, geom, Ho, Wo
         if self._c8p_ok(B, H, W, Cin, Cout, R, stride, pad) and (acc or not stats):
             a = self._acc(K.L.count("vqa_bn_acc_words", 2, Cout)) if stats else None
-            y = K.conv8p(x, self.Wm(wname), B, H, W, Cin, Cout, stats_acc=a)
+            y = K.conv8p(x, self.Wm(wname), B, H, W, Cin, Cout, stride=stride, stats_acc=a)
             return y, a, (-1 if a is not None else 0), geom, Ho, Wo
         a = self._acc(K.L.count("vqa_bn_acc_words", 2, Cout)) if (acc and stats) else None
         y, st, mt = K.igemm(x, self.Wm(wname), M, Cout, R * R * Cin, geom, dtype=self.dtype, want_stats=stats, stats_acc=a)
@@ -1085,7 +1085,7 @@ class HipEngine:
                 dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1, addend=dxd)
         elif c64_1 and not masked and outmask is None:
             dx, _, _ = K.conv3x3_c64(dy1, self._wflip(p + ".conv1.weight"), B, H, W, addend=dout, addmask=rec["out"])
-        elif self.use_conv8p_bwd and self._c8p_ok(B, H, W, Cout, Cin, 3, stride, 1):
+        elif self.use_conv8p_bwd and stride == 1 and self._c8p_ok(B, H, W, Cout, Cin, 3, stride, 1):
             dx = K.conv8p(dy1, self.Wt(p + ".conv1.weight"), B, H, W, Cout, Cin, transposed=1, addend=dout, addmask=out_act, outmask=outmask)
         else:
             dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
