@@ -276,7 +276,9 @@ int vqa_convert(int dtype_in, int dtype_out, const void* in, void* out, long lon
 int vqa_sumsq(const float* g, long long n, float* out /* >= 2049 floats: [0] result (bit-reproducible), rest scratch */, hipStream_t stream);
 int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, long long calls, const float* sumsq, float max_norm, float gscale,
-              const int* skip, int* skipped, hipStream_t stream);
+              const int* skip, int* skipped,
+              void* p_bf16 /* or NULL: also write the bf16 copy of the updated parameters (the operand buffer of the next forward) */,
+              hipStream_t stream);
 
 /* ---- input pipeline on the GPU -----------------------------------------------------------------
  * vqa_image_normalize: torchvision ToTensor + Normalize of data/preprocess.py:34-35,117-121 -- uint8 HWC [B][H][W][3] ->

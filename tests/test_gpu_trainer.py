@@ -95,6 +95,28 @@ def test_three_steps_track_the_oracle_trainer():
     assert tr.t == 3
 
 
+def test_fused_adamw_operand_copy_is_dropped_after_a_torch_side_write():
+    """Round 4: vqa_adamw also writes the bf16 operand copy of the parameters and the next HipTrainer.step skips the cast launch -- but only if
+    nothing wrote the parameters through torch in between.  load_state_dict between two steps must be SEEN by the next forward."""
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0, vocab_size=100, num_answers=10, embed_dim=32)
+    sd_a, sd_b = O.init_state_dict(cfg, 31, jitter=True), O.init_state_dict(cfg, 32, jitter=True)
+    batch = [t.to(DEV) for t in O.synthetic_batch(4, seed=900, image_size=64, seq_len=10, vocab=100, num_answers=10)]
+    m = _model(cfg, sd_a, dtype="bf16")
+    tr = pkg().trainer.HipTrainer(m, lr=1e-3)
+    tr.step(*batch); tr.step(*batch)
+    assert tr._copy_sig is not None                              # the second step trusted the copy written by the first one's AdamW
+    m.load_state_dict(sd_b)                                      # torch-side write of every parameter (copy_ into the views)
+    _, logits = tr.step(*batch)
+    ref = _model(cfg, sd_b, dtype="bf16")
+    _, logits_ref = pkg().trainer.HipTrainer(ref, lr=1e-3).step(*batch)
+    torch.cuda.synchronize()
+    assert torch.equal(logits, logits_ref)                       # the forward ran on sd_b's weights, not on a stale bf16 copy of the old ones
+    # and the copy the kernel writes is the cast of the fp32 parameters
+    tr.step(*batch)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.engine.wsrc, m._flat.to(torch.bfloat16))
+
+
 def test_skipped_step_then_more_steps_without_check_track_the_oracle():
     """VERDICT r3 #7 / ADVICE r3: one good step, one step with an out-of-range target (the reference raises inside the loss, after the
     forward has updated the BatchNorm buffers and before optimizer.step), then three more good steps and NO check() in between.
@@ -139,6 +161,7 @@ def test_skipped_step_then_more_steps_without_check_track_the_oracle():
     opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
     pd, md, vd = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     bad = torch.zeros(3, device=DEV, dtype=torch.int32)
+    pb = torch.zeros(n, device=DEV, dtype=torch.bfloat16)
     for call_no in range(1, 6):
         gr = torch.randn(n, generator=g) * 1e-3
         skip = torch.tensor([2 if call_no == 2 else 0], device=DEV, dtype=torch.int32)
@@ -146,7 +169,9 @@ def test_skipped_step_then_more_steps_without_check_track_the_oracle():
             pr.grad = gr.clone()
             opt.step()
         L.call("vqa_adamw", pd.data_ptr(), gr.to(DEV).data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.01,
-               call_no, None, 0.0, 1.0, skip.data_ptr(), bad.data_ptr())
+               call_no, None, 0.0, 1.0, skip.data_ptr(), bad.data_ptr(), pb.data_ptr())
+        if call_no != 2:
+            assert torch.equal(pb, pd.to(torch.bfloat16))             # the bf16 operand copy written by the same launch
     torch.cuda.synchronize()
     assert bad.tolist() == [2, 1, 1]
     assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6      # one step ahead would be off by ~lr * 0.1 = 1e-4 after the skip
@@ -246,7 +271,7 @@ def test_sumsq_clip_adamw_kernels_match_torch(clip_active, gscale):
         gd = gr.to(DEV)
         L.call("vqa_sumsq", gd.data_ptr(), n, ss.data_ptr())
         L.call("vqa_adamw", pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.01,
-               t, ss.data_ptr(), 1.0, gscale, None, None)
+               t, ss.data_ptr(), 1.0, gscale, None, None, None)
         torch.cuda.synchronize()
         assert abs(float(ss[0].sqrt()) * gscale - float(nrm)) / float(nrm) < 1e-5
         assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6

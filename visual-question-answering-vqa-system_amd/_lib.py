@@ -104,7 +104,7 @@ SIGNATURES = {
     "vqa_image_resize_ws": [I, P, P, I, I, I],
     "vqa_image_resize": [P, P, P, P, P, I, I, I, I, I, P, P, P, F, F, F, F, F, F, P, LL, P],
     "vqa_pack_tokens": [P, P, P, P, I, I, I, I, I, I, P],
-    "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, LL, P, F, F, P, P, P],
+    "vqa_adamw": [P, P, P, P, LL, F, F, F, F, F, LL, P, F, F, P, P, P, P],
 }
 _RET_LL = {"vqa_image_resize_ws", "vqa_wgrad_group_ws", "vqa_spatial_bwd_scratch", "vqa_se_bwd_scratch", "vqa_layernorm_bwd_ws", "vqa_bias_act_bwd_ws"}                       # return a size (long long)
 _NO_STATUS = _RET_LL | {"vqa_wgrad3x3_c64_blocks", "vqa_bn_acc_words", "vqa_bn_apply_pool_chunks", "vqa_se_bwd_blocks", "vqa_wgrad3x3_c128_blocks", "vqa_layernorm_bwd_folds", "vqa_bias_act_bwd_fold_rows", "vqa_conv3x3_c64p_blocks", "vqa_stem_wgrad_blocks", "vqa_igemm_mtiles", "vqa_igemm_variant", "vqa_bn_bwd_blocks", "vqa_stem_conv_blocks", "vqa_conv3x3_c64_blocks", "vqa_stem_conv_pool_ok", "vqa_wgrad3x3_c64_bn_ok", "vqa_conv8p_ok"}   # return a count, not a status

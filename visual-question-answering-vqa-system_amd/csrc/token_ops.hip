@@ -714,7 +714,10 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(float* out, int nparts
 // clip_grad_norm_(max_norm) + AdamW (decoupled weight decay), torch semantics (training/train.py:204-208,127-132)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
                              float lr, float b1, float b2, float eps, float wd, long long calls, const float* __restrict__ sumsq,
-                             float max_norm, float gscale, const int* __restrict__ skip, int* __restrict__ skipped) {
+                             float max_norm, float gscale, const int* __restrict__ skip, int* __restrict__ skipped, bf16_t* __restrict__ p_bf16) {
+  // p_bf16 != nullptr: the bf16 working copy of the parameters (what the next forward's GEMMs read) is written here as well -- the
+  // separate cast launch over the flat buffer (116 MB of traffic, 34 us at the head of every step) is gone.  A skipped launch leaves
+  // both the parameters and the copy as they were.
   // skip[0] != 0 (rows with an out-of-range target in THIS step, summed over ranks): the reference raises before
   // optimizer.step() (nn.CrossEntropyLoss, training/train.py:120,182-208) and leaves the model intact -- so does this kernel:
   // parameters and both moments stay untouched; skipped[0] += rows, skipped[1] += 1 (read by the host at its logging interval),
@@ -743,6 +746,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     m[i] = mi; v[i] = vi;
     pi -= step * mi / (sqrtf(vi) * rbc2 + eps);
     p[i] = pi;
+    if (p_bf16) p_bf16[i] = f2bf(pi);
   }
 }
 
@@ -990,11 +994,11 @@ int vqa_sumsq(const float* g, long long n, float* out, hipStream_t st) {
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
-              long long calls, const float* sumsq, float max_norm, float gscale, const int* skip, int* skipped, hipStream_t st) {
+              long long calls, const float* sumsq, float max_norm, float gscale, const int* skip, int* skipped, void* p_bf16, hipStream_t st) {
   if (calls < 1) return VQA_EARG;
   size_t blocks = ((size_t)n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, calls, sumsq, max_norm, gscale,
-                     skip, skipped);
+                     skip, skipped, (bf16_t*)p_bf16);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 

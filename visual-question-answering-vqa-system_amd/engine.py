@@ -76,6 +76,7 @@ class HipEngine:
         self.seed_rank = None
         self.step_id = 0
         self.wsrc = flat
+        self._wsrc_fresh = False                  # one-shot: the bf16 copy wsrc was written by the last fused AdamW launch (trainer.py)
         self._wt: Dict[str, torch.Tensor] = {}
         self._wt_plan: Dict[str, tuple] = {}      # operands packed by begin_step (filled by _packT on first use)
         self._wt_table = None
@@ -218,7 +219,12 @@ class HipEngine:
         if self.dtype == torch.bfloat16:
             if self.wsrc is self.flat or self.wsrc.numel() != self.flat.numel():
                 self.wsrc = torch.empty(self.flat.numel(), device=self.flat.device, dtype=torch.bfloat16)
-            call("vqa_convert", 0, 1, ptr(self.flat), ptr(self.wsrc), self.flat.numel())
+                self._wsrc_fresh = False
+            # HipTrainer's AdamW launch writes this copy itself (adamw_copy_target) and vouches for it for exactly ONE begin_step, after
+            # checking that nothing touched the parameters through torch in between (trainer._param_sig); every other caller casts
+            if not self._wsrc_fresh:
+                call("vqa_convert", 0, 1, ptr(self.flat), ptr(self.wsrc), self.flat.numel())
+            self._wsrc_fresh = False
         else:
             self.wsrc = self.flat
         bk = 64 if self.dtype == torch.bfloat16 else 32
@@ -229,6 +235,13 @@ class HipEngine:
         if self.dtype == torch.bfloat16:            # operand of the dedicated bf16 stem kernel: [64][(c,r,s8)]
             self.stem_w2 = torch.empty((64, 192), device=self.flat.device, dtype=torch.bfloat16)
             call("vqa_stem_pack", ptr(self.P("image_encoder.stem.0.weight")), ptr(self.stem_w2))
+
+    def adamw_copy_target(self):
+        """bf16 operand buffer the fused AdamW kernel may write next to the fp32 parameters (None: fp32 schedule / not allocated yet)."""
+        if self.dtype != torch.bfloat16 or self.wsrc is self.flat or self.wsrc.numel() != self.flat.numel():
+            return None
+        return self.wsrc
+
 
     def _seed(self):
         self._site += 1

@@ -160,6 +160,7 @@ class HipTrainer:
         self._bad = torch.zeros(3, device=flat.device, dtype=torch.int32)
         self.bad_targets = self._bad[:2]
         self.calls = 0
+        self._copy_sig = None                      # parameter-version signature right after the last fused AdamW launch
         self.buckets = LY.bucket_ranges(model._entries)
         self.reducer = GradBucketReducer(self.G, self.buckets, process_group, overlap, force=force_reducer,
                                          avoid_streams=[st for st in (self.engine.side, self.engine.side2) if st is not None])
@@ -185,6 +186,8 @@ class HipTrainer:
         targets = targets.contiguous().long()
         self.G.zero_()
         self._scal.zero_()
+        if self._copy_sig is not None and eng.adamw_copy_target() is not None and self._copy_sig == self._param_sig():
+            eng._wsrc_fresh = True                 # (one-shot, consumed by the begin_step of the forward below)
         maskf = None if attention_mask is None else attention_mask.contiguous().float()
         logits_f, _, tape = eng.forward(images, token_ids, maskf, True, False, need_tape=True)
         B, N = logits_f.shape
@@ -201,8 +204,21 @@ class HipTrainer:
         self.calls += 1
         b1, b2 = self.betas
         call("vqa_adamw", ptr(self.model._flat), ptr(self.G), ptr(self.m), ptr(self.v), self.G.numel(), self.lr, b1, b2, self.eps,
-             self.wd, self.calls, ptr(self.sumsq), float(self.max_norm), gscale, ptr(self.bad_step), ptr(self._bad))
+             self.wd, self.calls, ptr(self.sumsq), float(self.max_norm), gscale, ptr(self.bad_step), ptr(self._bad), ptr(eng.adamw_copy_target()))
+        # the kernel wrote the bf16 operand copy too: the next step() skips the cast launch if nothing touched the parameters in between
+        self._copy_sig = self._param_sig() if eng.adamw_copy_target() is not None else None
         return self.loss, logits_f
+
+    def params_changed(self):
+        """Tell the trainer that the parameters were written behind torch's back (through `.data`, a raw pointer, another C-ABI call):
+        the next step re-casts the bf16 operand copy instead of trusting the one the last AdamW launch wrote.  Writes through torch
+        (load_state_dict, optimizers, in-place ops on the Parameters or the flat buffer) are noticed without this call."""
+        self._copy_sig = None
+
+    def _param_sig(self):
+        """Version counters of the flat buffer and of every Parameter view: any torch-side write (load_state_dict, an optimizer, .copy_)
+        bumps one of them.  (The C-ABI kernels do not: the fused AdamW launch is the one writer this class accounts for itself.)"""
+        return (self.model._flat.data_ptr(), self.model._flat._version) + tuple(p._version for p in self.model._param_list())
 
     @property
     def t(self) -> int:
