@@ -328,6 +328,15 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   G8_BAR();
   if (grp == 1) G8_BAR();                                           // group 1 runs one barrier behind group 0 from here on
 
+  // The A-first fragments of K tile t + 1 are read in P4 of tile t (their registers are free after P2's MFMAs): the fragment reads of
+  // the four load segments are 4 / 4 / 6 / 8 instead of 12 / 4 / 6 / 0 (round 4: the 12-read P1 segment was the longest interval).
+  // Hence A first (t + 1) is waited for in P3 (t) and read one phase later; it is restaged in P3 (t + 1), three phases after that read.
+#define C8_RD_AT(dst, dd, off) dst = *reinterpret_cast<const bf16x8*>(smem + (dd) * G::BUF + (off))
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) C8_RD_AT(a0[i][kk], 0, ra0 + i * 2048 + sk[kk]);
+
   for (int t = 0; t < nkt; ++t) {
     const int d = t & 1;
     // ---------------- P1: rows 0-63 of the wave x columns 0-31
@@ -335,13 +344,8 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD(b0[j][kk], rb0 + j * 2048 + sk[kk]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) C8_RD(a0[i][kk], ra0 + i * 2048 + sk[kk]);
     stage(3, t + 1);
-    C8_WAIT();
+    C8_WAIT();                                                      // B second (t) landed -> read in P2
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     G8_COMPUTE(a0, b0, 0, 0, 4);
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD(b1[j][kk], rb1 + j * 2048 + sk[kk]);
     stage(1, t + 1);
-    C8_WAIT();
+    C8_WAIT();                                                      // A second (t) landed -> read in P3
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     G8_COMPUTE(a0, b1, 0, 2, 4);
@@ -363,17 +367,24 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD(a1[i][kk], ra1 + i * 2048 + sk[kk]);
     stage(0, t + 2);
+    C8_WAIT();                                                      // A first (t + 1) landed -> read in P4
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     G8_COMPUTE(a1, b1, 4, 2, 3);
     G8_BAR();
-    // ---------------- P4: rows 64-111 x columns 0-31
+    // ---------------- P4: rows 64-111 x columns 0-31; the A-first fragments of the NEXT K tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) C8_RD_AT(a0[i][kk], d ^ 1, ra0 + i * 2048 + sk[kk]);
     stage(2, t + 2);
-    C8_WAIT();
+    C8_WAIT();                                                      // B first (t + 1) landed -> read in P1 of the next K tile
     G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     G8_COMPUTE(a1, b0, 4, 0, 3);
     G8_BAR();
   }
+#undef C8_RD_AT
   if (grp == 0) G8_BAR();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the out-of-range tail pieces have written their zeros
   G8_BAR();
