@@ -185,6 +185,71 @@ def test_engine_runs_the_fused_schedule_and_matches_the_unfused_one():
     assert float((g1 - g0).norm() / g0.norm()) < 2e-2
 
 
+def _bf16_step(cfg, sd, batch, dlogits_scale=1.0, **switches):
+    """One bf16 forward + backward of the full model through the engine (no optimizer): (logits, flat gradient)."""
+    from _pkg import pkg
+    P, L = pkg(), sub("_lib")
+    m = P.load_dropin().VQAModel(**cfg, compute_dtype="bf16")
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    eng = m._ensure_engine()
+    for k, v in switches.items():
+        assert hasattr(eng, k), k
+        setattr(eng, k, v)
+    images, ids, mask, answers = batch
+    logits, _, tape = eng.forward(images, ids, mask.float(), True, False, need_tape=True)
+    B, N = logits.shape
+    dl = torch.empty_like(logits); loss = torch.zeros(1, device=DEV); ws = torch.empty(B, device=DEV)
+    L.call("vqa_cross_entropy", 0, logits.data_ptr(), answers.data_ptr(), loss.data_ptr(), dl.data_ptr(), None, B, N, float(dlogits_scale), None, ws.data_ptr())
+    G = torch.zeros_like(m._flat)
+    eng.backward(tape, dl, G)
+    torch.cuda.synchronize()
+    return logits, G
+
+
+def test_bf16_step_with_and_without_the_round4_kernels():
+    """hold the bf16 whole-model step against THE SAME ENGINE with a fusion / kernel switched off, where the bound
+    can be tight instead of the bf16-vs-fp32 noise floor.
+      * fuse_bn_conv (stage-1 conv2 and its weight gradient on the un-materialised relu(bn1(y1))) is bit-identical at kernel level, so the
+        whole gradient vector must be torch.equal with it on and off;
+      * use_conv8p swaps the GEMM tile of the stage-3/4 convs: same operands, fp32 sums in another order -> bf16 re-rounding of a few
+        elements, which train-mode BatchNorm at B = 16 amplifies: measured 7.9 % of the gradient norm between the two valid bf16
+        schedules; bound 15 % (the bf16-vs-fp32 bounds of test_gpu_model.py are 45-75 %; a wiring error -- wrong tap, mirrored weights,
+        missing addend -- is O(1)), logits within 2e-2."""
+    from oracle import vqa_oracle as O
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0)
+    sd = O.init_state_dict(cfg, 5, jitter=True)
+    batch = [t.to(DEV) for t in O.synthetic_batch(16, seed=77)]
+    l_ref, g_ref = _bf16_step(cfg, sd, batch)
+    l_a, g_a = _bf16_step(cfg, sd, batch, fuse_bn_conv=False)
+    assert torch.equal(l_a, l_ref) and torch.equal(g_a, g_ref)
+    l_b, g_b = _bf16_step(cfg, sd, batch, use_conv8p=False)
+    assert (l_b - l_ref).abs().max().item() < 2e-2
+    assert float((g_b - g_ref).norm() / g_ref.norm()) < 0.15
+    l_c, g_c = _bf16_step(cfg, sd, batch)                            # and the step itself is bit-reproducible
+    assert torch.equal(l_c, l_ref) and torch.equal(g_c, g_ref)
+
+
+@pytest.mark.parametrize("log2_scale", [16, 24])
+def test_bf16_backward_is_linear_in_the_loss_scale(log2_scale):
+    """The whole bf16 backward under a power-of-two loss scale (GradScaler's 2^16 ... ): every bf16 rounding and every fixed-point sum is
+    scale-invariant for powers of two (no overflow, no subnormals at these magnitudes), so G(scale * dlogits) must equal scale * G(dlogits)
+    -- to a few ulp where a 2^-50 fixed-point plane rounds differently.  A saturating / wrapping accumulator or a mis-scaled epilogue
+    shows up as a relative error of O(1) in some tensor."""
+    from oracle import vqa_oracle as O
+    cfg = O.full_config(dropout=0.0, answer_dropout=0.0)
+    sd = O.init_state_dict(cfg, 6, jitter=True)
+    batch = [t.to(DEV) for t in O.synthetic_batch(8, seed=78)]
+    _, g1 = _bf16_step(cfg, sd, batch)
+    s = float(2 ** log2_scale)
+    _, gs = _bf16_step(cfg, sd, batch, dlogits_scale=s)
+    assert torch.isfinite(gs).all()
+    rel = float((gs / s - g1).norm() / g1.norm())
+    assert rel < 1e-3, rel
+    frac_exact = float((gs / s == g1).float().mean())
+    assert frac_exact > 0.9, frac_exact
+
+
 # ---- BatchNorm finalize folded into the consumers: statistics and backward sums as fixed-point integer accumulators -------------
 def _bn_ref_coef(y, gamma, beta, eps=1e-5):
     yf = y.double()
