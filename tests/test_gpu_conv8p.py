@@ -1,6 +1,6 @@
-"""The 8-phase GEMM core (csrc/gemm8p.hip): dense GEMM against fp32 matmul, and the implicit-GEMM 3x3 conv / data gradient against
-ATen convolutions on the same bf16 operands and BIT-comparable against the 128x128 igemm tile's fp32 accumulation order is NOT
-expected (different K order inside a tile) -- the bound is the bf16 rounding of the stored value."""
+"""The 8-phase GEMM core (csrc/gemm8p.hip): dense GEMM against fp32 matmul; the implicit-GEMM 3x3 conv (stride 1, 2) and data gradient
+against ATen convolutions on the same bf16 operands and against the 128x128 igemm tile.  Bit-equality with igemm is not expected (the
+fp32 sums run over K in another order); the bound is the bf16 rounding of the stored value.  Models: models/cnn_backbone.py:182-187."""
 import pytest
 import torch
 import torch.nn.functional as F

@@ -14,35 +14,14 @@ def dropin_path() -> str:
 
 
 def load_dropin():
-    """Import the drop-in `models.vqa_model` without disturbing an already imported `models` package."""
-    import importlib.util
-    import os
-    import sys
-    name = "vqa_hip_dropin_models_vqa_model"
-    if name in sys.modules:
-        return sys.modules[name]
-    path = os.path.join(dropin_path(), "models", "vqa_model.py")
-    spec = importlib.util.spec_from_file_location(name, path)
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules[name] = mod
-    spec.loader.exec_module(mod)
-    return mod
+    """Import the drop-in `models.vqa_model` under a private name, without disturbing an already imported `models` package
+    (tests and the harness use this; a CALLER of the reference reaches the drop-in through binding.bind() / run_reference.py)."""
+    return _load_dropin_file("vqa_hip_dropin_models_vqa_model", "models", "vqa_model.py")
 
 
 def load_dropin_metrics():
-    """Import the drop-in `utils.metrics` (device-side VQAAccuracy) without disturbing an already imported `utils` package."""
-    import importlib.util
-    import os
-    import sys
-    name = "vqa_hip_dropin_utils_metrics"
-    if name in sys.modules:
-        return sys.modules[name]
-    path = os.path.join(dropin_path(), "utils", "metrics.py")
-    spec = importlib.util.spec_from_file_location(name, path)
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules[name] = mod
-    spec.loader.exec_module(mod)
-    return mod
+    """The drop-in `utils.metrics` (device-side VQAAccuracy), without disturbing an already imported `utils` package."""
+    return _load_dropin_file("vqa_hip_dropin_utils_metrics", "utils", "metrics.py")
 
 
 def _load_dropin_file(name, *rel):

@@ -105,6 +105,11 @@ class HipEngine:
         # round 4: 3x3 / stride-1 convs and data gradients with >= 256 output channels (stages 3, 4) on the 8-phase 224 x 256 tile
         # (csrc/gemm8p.hip: one 8-wave workgroup per CU, staggered wave groups; 196-of-224-row tiles = exact rounds at B = 512)
         self.use_conv8p = True
+        # output channels a multiple of: 128 also routes stage 2 to the 448 x 128 form of the tile.  In isolation that form ties the
+        # 128 x 128 window-loader tile there (155 / 143 vs 159 / 137 us); IN THE STEP it is faster: 12.35 -> 12.29 ms with both directions,
+        # 12.31 forward only, 12.33 backward only (tools/ab_fusions.py, three alternations on one box; a second box: 12.73 -> 12.64)
+        self.conv8p_n_multiple = 128
+        self.conv8p_bwd_n_multiple = 128
         self.use_conv8p_bwd = True                # ... also for the data gradients (they run beside the weight-gradient stream)
         self._accbuf = None
         self._accpos = 0
@@ -294,11 +299,10 @@ class HipEngine:
         return (self.dtype == torch.bfloat16 and Cin == 64 and Cout == 64 and R == 3 and stride == 1 and K.c64p_blocks(B, H, W) > 0
                 and self.use_c64p)
 
-    def _c8p_ok(self, B, H, W, Cin, Cout, R, stride, pad):
-        """3x3 / 1 / pad 1 conv (or stride-1 data gradient) routed to the 8-phase 224 x 256 tile: bf16, output channels a multiple of 256 (stages
-        3 and 4).  The 448 x 128 form of the kernel (N = 128: stage 2) is parity-tested but NOT routed: 167 / 150 us against 168 / 140 us for
-        the 128 x 128 window-loader tile at B = 512 (K = 1152 is only 18 K tiles; profiles/r04_gemm8p_bench.txt)."""
-        return (self.use_conv8p and self.dtype == torch.bfloat16 and R == 3 and stride in (1, 2) and pad == 1 and Cout % 256 == 0
+    def _c8p_ok(self, B, H, W, Cin, Cout, R, stride, pad, bwd=False):
+        """3x3 / pad 1 conv (stride 1 or 2) or stride-1 data gradient routed to the 8-phase tile: bf16, output channels a multiple of 256
+        (224 x 256 tile: stages 3, 4) or of 128 (448 x 128 tile: stage 2)."""
+        return (self.use_conv8p and self.dtype == torch.bfloat16 and R == 3 and stride in (1, 2) and pad == 1 and Cout % (self.conv8p_bwd_n_multiple if bwd else self.conv8p_n_multiple) == 0
                 and K.conv8p_ok(B, H, W, Cin, Cout))
 
     def _wflip(self, name):                  # [Cin][(2-r,2-s)][Cout] operand of the stride-1 data gradient as a plain 3x3 conv
@@ -1066,7 +1070,7 @@ class HipEngine:
             da1, _, _ = K.conv3x3_c64p(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
         elif c64_2:
             da1, _, _ = K.conv3x3_c64(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
-        elif self.use_conv8p_bwd and self._c8p_ok(B, Ho, Wo, Cout, Cout, 3, 1, 1):
+        elif self.use_conv8p_bwd and self._c8p_ok(B, Ho, Wo, Cout, Cout, 3, 1, 1, bwd=True):
             da1 = K.conv8p(dy2, self.Wt(p + ".conv2.weight"), B, Ho, Wo, Cout, Cout, transposed=1)
         else:
             geom_d2 = (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
@@ -1098,7 +1102,7 @@ class HipEngine:
                 dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1, addend=dxd)
         elif c64_1 and not masked and outmask is None:
             dx, _, _ = K.conv3x3_c64(dy1, self._wflip(p + ".conv1.weight"), B, H, W, addend=dout, addmask=rec["out"])
-        elif self.use_conv8p_bwd and stride == 1 and self._c8p_ok(B, H, W, Cout, Cin, 3, stride, 1):
+        elif self.use_conv8p_bwd and stride == 1 and self._c8p_ok(B, H, W, Cout, Cin, 3, stride, 1, bwd=True):
             dx = K.conv8p(dy1, self.Wt(p + ".conv1.weight"), B, H, W, Cout, Cin, transposed=1, addend=dout, addmask=out_act, outmask=outmask)
         else:
             dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
