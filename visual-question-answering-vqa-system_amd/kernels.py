@@ -213,7 +213,8 @@ def conv8p(x, w, B, H, W, C, N, *, transposed=0, stride=1, stats_acc=None, out=N
     call("vqa_conv8p", ptr(x), ptr(w), ptr(out), ptr(stats_acc), ptr(addend), ptr(addmask), ptr(outmask), B, H, W, C, N, int(transposed), int(stride))
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("conv8p_kernel", 2.0 * out.shape[0] * N * 9 * C, e0, e1, (B * H * W * C + out.shape[0] * N + N * 9 * C) * 2))
+        PROFILE.append(("conv8p_kernel<2, 4>" if N % 256 == 0 else "conv8p_kernel<4, 2>",      # the symbol rocprofv3 prints (the C dispatch: 256 | N)
+                        2.0 * out.shape[0] * N * 9 * C, e0, e1, (B * H * W * C + out.shape[0] * N + N * 9 * C) * 2))
     return out
 
 
