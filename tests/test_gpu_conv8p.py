@@ -98,6 +98,32 @@ def test_conv8p_matches_aten(B, H, W, C, N, transposed):
             if "outmask" in kw:
                 e = e * (om.float() > 0)
             assert torch.equal(o3.float(), e), kw.keys()
+        # the BatchNorm-backward column sums of the stored tile (bn1 behind conv2's data gradient): same output bits, and the sums of
+        # vqa_bn_bwd_reduce(self_mask) over (that output, y) -- equal as exact fixed-point totals up to the fp32 rounding of the partials
+        y = torch.randn(B * H * W, N, generator=g).to(DEV, bf)
+        coef = torch.stack([torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.3, torch.randn(N, generator=g) * 0.1,
+                            torch.rand(N, generator=g) + 0.5]).to(DEV).contiguous()
+        words = L.count("vqa_bn_acc_words", 3, N)
+        for kw in (dict(), dict(outmask=om)):
+            facc, fref = torch.zeros(words, device=DEV, dtype=torch.int64), torch.zeros(words, device=DEV, dtype=torch.int64)
+            o4 = K.conv8p(x, wt.view(N, 9 * C), B, H, W, C, N, transposed=1, bnred=(y, coef, facc), **kw)
+            o5 = K.conv8p(x, wt.view(N, 9 * C), B, H, W, C, N, transposed=1, **kw)
+            assert torch.equal(o4, o5)
+            R = max(1, min(8, 512 // N))
+            s4, f4 = _acc_decode(facc, R, 3, N)
+            s5, f5 = s4, 0
+            if 256 % (N // 8) == 0:                                              # (the row-block kernel's own shape rule; the model's widths all pass)
+                L.call("vqa_bn_bwd_reduce", L.dt(bf), o5.data_ptr(), None, y.data_ptr(), coef.data_ptr(), None, None, fref.data_ptr(), B * H * W, N, 1, 1)
+                s5, f5 = _acc_decode(fref, R, 3, N)
+            gm = o5.double() * ((y.double() * coef[0].double() + coef[1].double()) > 0)          # (the mask itself is taken in fp32 on both sides)
+            e0, e1 = gm.sum(0), (gm * (y.double() - coef[2].double()) * coef[3].double()).sum(0)
+            assert f4 == 0 and f5 == 0
+            for k, e in ((0, e0), (1, e1)):
+                scale = max(1.0, float(gm.abs().sum(0).max()))
+                assert (s4[k] - s5[k]).abs().max().item() <= 2e-5 * scale and (s4[k] - e).abs().max().item() <= 1e-3 * scale, (k, kw.keys())
+            assert s4[2].abs().max().item() == 0
+        with pytest.raises(RuntimeError):                                        # all three or none
+            L.call("vqa_conv8p", x.data_ptr(), wt.data_ptr(), out.data_ptr(), None, None, None, None, y.data_ptr(), None, None, B, H, W, C, N, 1, 1)
     if not transposed:
         R = max(1, min(8, 512 // N))
         sums, flag = _acc_decode(acc, R, 2, N)

@@ -110,6 +110,7 @@ class HipEngine:
         # 12.31 forward only, 12.33 backward only (tools/ab_fusions.py, three alternations on one box; a second box: 12.73 -> 12.64)
         self.conv8p_n_multiple = 128
         self.conv8p_bwd_n_multiple = 128
+        self.fuse_bn1_reduce = True               # bn1-backward column sums in the epilogue of conv2's data gradient (conv8p)
         self.use_conv8p_bwd = True                # ... also for the data gradients (they run beside the weight-gradient stream)
         self._accbuf = None
         self._accpos = 0
@@ -1065,19 +1066,23 @@ class HipEngine:
             self._off_path([dy2], lambda: K.wgrad3x3_c128(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo))
         else:
             self._off_path([dy2], lambda: K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T))
-        slab1, nb1 = None, 0
+        slab1, nb1, facc1 = None, 0, None
         if self._c64p_ok(B, Ho, Wo, Cout, Cout, 3, 1):
             da1, _, _ = K.conv3x3_c64p(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
         elif c64_2:
             da1, _, _ = K.conv3x3_c64(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
         elif self.use_conv8p_bwd and self._c8p_ok(B, Ho, Wo, Cout, Cout, 3, 1, 1, bwd=True):
-            da1 = K.conv8p(dy2, self.Wt(p + ".conv2.weight"), B, Ho, Wo, Cout, Cout, transposed=1)
+            if bacc and self.fuse_bn1_reduce:     # bn1's backward column sums leave the data-gradient epilogue: no bn_bwd_reduce pass over (da1, y1)
+                facc1 = self._acc(K.L.count("vqa_bn_acc_words", 3, Cout))
+            da1 = K.conv8p(dy2, self.Wt(p + ".conv2.weight"), B, Ho, Wo, Cout, Cout, transposed=1,
+                           bnred=(rec["y1"], rec["c1"], facc1) if facc1 is not None else None)
         else:
             geom_d2 = (B, Ho, Wo, Cout, Ho, Wo, 3, 3, 1, 1)
             da1, _, _ = K.igemm(dy2, self.Wt(p + ".conv2.weight"), M, Cout, 9 * Cout, geom_d2, dtype=T, transposed=1)
         dy1, _ = K.bn_bwd(da1, None, rec["y1"], rec["c1"], self.P(p + ".bn1.weight"), Cout, training,
                           gs(p + ".bn1.weight"), gs(p + ".bn1.bias"), self_mask=True,      # a1 > 0 recomputed from y1: a1 is not read
-                          slab=slab1, nb=nb1, facc=self._acc(K.L.count("vqa_bn_acc_words", 3, Cout)) if bacc else None)
+                          slab=slab1, nb=nb1, facc=facc1 if facc1 is not None else (self._acc(K.L.count("vqa_bn_acc_words", 3, Cout)) if bacc else None),
+                          facc_filled=facc1 is not None)
         g1 = rec["g1"]; H, W, stride = g1[1], g1[2], g1[8]
         c64_1 = self._c64_ok(B, H, W, Cin, Cout, 3, stride)
         if self._c64_ok(B, H, W, Cin, Cout, 3, stride, wgrad=True):

@@ -203,14 +203,16 @@ def conv8p_ok(B, H, W, C, N) -> bool:
     return L.count("vqa_conv8p_ok", B, H, W, C, N) > 0
 
 
-def conv8p(x, w, B, H, W, C, N, *, transposed=0, stride=1, stats_acc=None, out=None, addend=None, addmask=None, outmask=None):
+def conv8p(x, w, B, H, W, C, N, *, transposed=0, stride=1, stats_acc=None, out=None, addend=None, addmask=None, outmask=None, bnred=None):
     """3x3 / 1 / pad 1 conv (or its stride-1 data gradient) on the 8-phase 224(196) x 256 x 64 tile (csrc/gemm8p.hip).  bf16 NHWC."""
     if out is None:
         out = torch.empty((B * ((H - 1) // stride + 1) * ((W - 1) // stride + 1), N), device=x.device, dtype=torch.bfloat16)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("vqa_conv8p", ptr(x), ptr(w), ptr(out), ptr(stats_acc), ptr(addend), ptr(addmask), ptr(outmask), B, H, W, C, N, int(transposed), int(stride))
+    bn_y, bn_coef, bn_facc = bnred if bnred is not None else (None, None, None)      # fused BatchNorm-backward column sums of the stored tile
+    call("vqa_conv8p", ptr(x), ptr(w), ptr(out), ptr(stats_acc), ptr(addend), ptr(addmask), ptr(outmask), ptr(bn_y), ptr(bn_coef), ptr(bn_facc),
+         B, H, W, C, N, int(transposed), int(stride))
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("conv8p_kernel<2, 4>" if N % 256 == 0 else "conv8p_kernel<4, 2>",      # the symbol rocprofv3 prints (the C dispatch: 256 | N)
