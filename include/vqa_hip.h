@@ -62,6 +62,10 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
 /* same conv (forward, or data gradient with the flipped pack) without epilogue inputs: 8-wave persistent kernel, 8 output rows per
  * block, input patches by LDS-DMA, weights in registers; stats [vqa_conv3x3_c64p_blocks][2][64] or NULL.  H % 8 == 0, W % 8 == 0. */
 int vqa_conv3x3_c64p_blocks(int B, int H, int W);
+/* ... and the data gradient of a residual block's conv1 (w = flipped + transposed pack) with the identity path in the epilogue:
+ * out = (conv + addend * (addmask > 0)) * (outmask > 0) on the bf16 conv value, as vqa_igemm / vqa_conv8p; addend required, masks or NULL. */
+int vqa_conv3x3_c64p_epi(const void* x, const void* w, void* out, const void* addend, const void* addmask, const void* outmask,
+                         int B, int H, int W, hipStream_t stream);
 int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W,
                      int stats_mode /* 1: stats is the fixed-point accumulator u64 [2*64 + 1] of vqa_bn_apply_acc */, hipStream_t stream);
 /* Round 4 -- the 256 x 256 x 64 8-phase GEMM core (csrc/gemm8p.hip): C[M][N] = A[M][K] . B[N][K]^T, bf16 operands, fp32 accumulation,

@@ -232,6 +232,11 @@ def test_bf16_step_with_and_without_the_round4_kernels():
     l_d, g_d = _bf16_step(cfg, sd, batch, fuse_bn1_reduce=False)
     assert torch.equal(l_d, l_ref)
     assert float((g_d - g_ref).norm() / g_ref.norm()) < 0.03
+    # use_c64p_epi: stage 1's conv1 data gradients on the patch kernel instead of the 128 x 64 igemm tile (other summation order, like
+    # use_conv8p but backward only)
+    l_e, g_e = _bf16_step(cfg, sd, batch, use_c64p_epi=False)
+    assert torch.equal(l_e, l_ref)
+    assert float((g_e - g_ref).norm() / g_ref.norm()) < 0.15
     l_c, g_c = _bf16_step(cfg, sd, batch)                            # and the step itself is bit-reproducible
     assert torch.equal(l_c, l_ref) and torch.equal(g_c, g_ref)
 

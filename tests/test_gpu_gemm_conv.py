@@ -357,6 +357,17 @@ def test_conv3x3_c64_dma_patch_kernel(case):
     dx, _, _ = K.conv3x3_c64p(nhwc(dy), wflip, B, H, W)
     torch.cuda.synchronize()
     assert _relerr(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1).reshape(-1, 64)) < _tol(dtype)
+    # the conv1 data gradient of a residual block: identity-path gradient and ReLU masks in the per-tile epilogue -- the bf16 conv value
+    # (bit-identical to the epilogue-free launch) + addend * (addmask > 0), re-rounded, then masked: vqa_igemm's epilogue bit for bit
+    add, am, om = (nhwc(torch.randn(B, 64, H, W, generator=g)).view(-1, 64) for _ in range(3))
+    for kw in (dict(), dict(addmask=am), dict(outmask=om), dict(addmask=am, outmask=om)):
+        d2 = K.conv3x3_c64p_epi(nhwc(dy), wflip, B, H, W, addend=add, **kw)
+        e = (dx.float() + (add.float() * (am.float() > 0) if "addmask" in kw else add.float())).to(dtype).float()
+        if "outmask" in kw:
+            e = e * (om.float() > 0)
+        assert torch.equal(d2.float(), e), kw.keys()
+    with pytest.raises(RuntimeError):
+        sub("_lib").call("vqa_conv3x3_c64p_epi", dy.data_ptr(), wflip.data_ptr(), dx.data_ptr(), None, None, None, B, H, W)
     assert K.c64p_blocks(2, 10, 10) == 0 and K.c64p_blocks(2, 6, 16) == 0 and K.c64p_blocks(2, 8, 128) == 0   # refused, not mangled
 
 

@@ -27,6 +27,7 @@ __device__ __forceinline__ int patch_off(int prow, int pcol, int chunk, int PWc)
 
 struct C64Params {
   const bf16_t* x; const bf16_t* w; bf16_t* out; float* stats; const bf16_t* addend; const bf16_t* addmask;
+  const bf16_t* outmask;     // 8-wave kernel, EPI variant: out = (conv + addend * (addmask > 0)) * (outmask > 0)  (addmask, outmask optional)
   int stats_mode;            // 1: stats is a fixed-point accumulator u64 [vqa_bn_acc_words(2, 64)] (common.h acc_add_fixed), not a per-workgroup slab
   int B, H, W; unsigned x_bytes;
   int dbg;                        // VQA_C64P_DBG (measurement only, wrong results): bit 0 no epilogue, bit 1 no MFMA loop, bit 2 no in-loop DMA
@@ -253,7 +254,11 @@ __device__ __forceinline__ void dma16_c64(i32x4_c64 rs, unsigned lds_addr, int v
 }
 }
 
-template <int RBP>
+// EPI (round 4): the data gradient of a residual block's conv1 with the identity-path gradient and the ReLU masks in the epilogue
+// (engine._block_bwd; vqa_igemm's epilogue on the bf16 conv value, bit for bit).  A lane's three 16-byte epilogue loads are issued at
+// the top of its tile, ~36 MFMAs ahead of their use; the waits the compiler counts for them also cover the (older, hidden) DMA pieces
+// of the prefetch, which at one tile's distance have landed.  No statistics in this variant: their 16 registers hold the loads.
+template <int RBP, bool EPI>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PWc = p.W + 2;
@@ -351,6 +356,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
     }
     for (int mt = wm; mt < mtiles; mt += 4) {
       tile_addr(mt + 4 < mtiles ? mt + 4 : mt, en, orow_n, ow_n);   // the block's last tile re-reads itself (drained at the barrier)
+      const size_t ooff = (((size_t)b * p.H + oh0 + orow) * p.W + ow) * CH + wn * 32 + 8 * g;
+      Vec16<bf16_t> e_a, e_m, e_o;
+      if (EPI) {
+        e_a = ldg16(p.addend + ooff);
+        if (p.addmask) e_m = ldg16(p.addmask + ooff);
+        if (p.outmask) e_o = ldg16(p.outmask + ooff);
+      }
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int kk = 0; kk < 18; ++kk) {
@@ -373,11 +385,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) { const float v = acc[nt][rr]; ssum[4 * nt + rr] += v; ssq[4 * nt + rr] += v * v; }
+        for (int rr = 0; rr < 4; ++rr) { if (EPI) break; const float v = acc[nt][rr]; ssum[4 * nt + rr] += v; ssq[4 * nt + rr] += v * v; }
         o[2 * nt] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){acc[nt][0], acc[nt][1]}, bf16x2_t));
         o[2 * nt + 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){acc[nt][2], acc[nt][3]}, bf16x2_t));
       }
-      *reinterpret_cast<u32x4*>(p.out + (((size_t)b * p.H + oh0 + orow_c) * p.W + ow_c) * CH + wn * 32 + 8 * g) = o;
+      if (EPI) {
+        Vec16<bf16_t> v; v.raw = o;
+        if (p.addmask) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v.set(j, v.get(j) + (e_m.get(j) > 0.f ? e_a.get(j) : 0.f));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v.set(j, v.get(j) + e_a.get(j));
+        }
+        if (p.outmask) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (!(e_o.get(j) > 0.f)) v.set(j, 0.f);
+        }
+        o = v.raw;
+      }
+      (void)orow_c; (void)ow_c;
+      *reinterpret_cast<u32x4*>(p.out + ooff) = o;
     }
     // next patch landed.  vmcnt retires in issue order and this wave issued its DMA pieces BEFORE its output stores: with at
     // least 4 stores behind them, "at most 4 outstanding" already proves the pieces are in LDS -- the stores keep draining
@@ -386,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  if (p.stats) {
+  if (!EPI && p.stats) {
     // fold the 16 pixels (lanes li) of each channel group, then the 4 m-waves through LDS, in a fixed order
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -974,7 +1002,7 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
   if (!x || !w || !out || grid <= 0) return VQA_EARG;
   C64Params p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
-  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.B = B; p.H = H; p.W = W; p.dbg = 0; p.stats_mode = 0; p.pre_mode = 0; p.pre_coef = nullptr;
+  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.outmask = nullptr; p.B = B; p.H = H; p.W = W; p.dbg = 0; p.stats_mode = 0; p.pre_mode = 0; p.pre_coef = nullptr;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb;
@@ -1002,7 +1030,7 @@ int vqa_conv3x3_c64p_blocks(int B, int H, int W) {
 static int c64p_launch(C64Params& p, const void* x, const void* w, void* out, float* stats, int B, int H, int W, int stats_mode, hipStream_t st) {
   const int grid = vqa_conv3x3_c64p_blocks(B, H, W);
   if (!x || !w || !out || grid <= 0) return VQA_EARG;
-  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats; p.addend = nullptr; p.addmask = nullptr;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
   p.B = B; p.H = H; p.W = W; p.stats_mode = stats_mode;
   const int dbg_env = vqa_env_int("VQA_C64P_DBG", 0);
   p.dbg = dbg_env;
@@ -1012,19 +1040,30 @@ static int c64p_launch(C64Params& p, const void* x, const void* w, void* out, fl
   const int rbp = c64p_rows(H, W);
   const size_t shm = (size_t)2 * (rbp + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4 + 2 * 64 * 4;
   static size_t attr8 = 0, attr4 = 0;
-  if (rbp == 8) {
-    if (shm > attr8) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64p_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr8 = shm; }
-    hipLaunchKernelGGL(conv3x3_c64p_kernel<8>, dim3(grid), dim3(512), shm, st, p);
-  } else {
-    if (shm > attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr4 = shm; }
-    hipLaunchKernelGGL(conv3x3_c64p_kernel<4>, dim3(grid), dim3(512), shm, st, p);
-  }
+  static size_t attr[4] = {0, 0, 0, 0};
+#define C64P_GO(RB, EP, SLOT) do { auto kfn = conv3x3_c64p_kernel<RB, EP>; \
+    if (shm > attr[SLOT]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr[SLOT] = shm; } \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), shm, st, p); } while (0)
+  if (p.addend) { if (rbp == 8) C64P_GO(8, true, 2); else C64P_GO(4, true, 3); }
+  else { if (rbp == 8) C64P_GO(8, false, 0); else C64P_GO(4, false, 1); }
+#undef C64P_GO
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, int stats_mode, hipStream_t st) {
   C64Params p;
-  p.pre_mode = 0; p.pre_coef = nullptr;
+  p.pre_mode = 0; p.pre_coef = nullptr; p.addend = p.addmask = p.outmask = nullptr;
   return c64p_launch(p, x, w, out, stats, B, H, W, stats_mode, st);
+}
+// The data gradient of a residual block's conv1 (w = the flipped + transposed pack) with the block's identity path in the epilogue:
+// out = (conv + addend * (addmask > 0)) * (outmask > 0) on the bf16 conv value, the epilogue of vqa_igemm / vqa_conv8p.  addend required;
+// addmask / outmask [B*H*W][64] bf16 or NULL.
+int vqa_conv3x3_c64p_epi(const void* x, const void* w, void* out, const void* addend, const void* addmask, const void* outmask,
+                         int B, int H, int W, hipStream_t st) {
+  if (!addend) return VQA_EARG;
+  C64Params p;
+  p.pre_mode = 0; p.pre_coef = nullptr;
+  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.outmask = (const bf16_t*)outmask;
+  return c64p_launch(p, x, w, out, nullptr, B, H, W, 0, st);
 }
 // The same conv applied to relu(BatchNorm(y)) in TRAINING mode, the normalised tensor never materialised (models/cnn_backbone.py:182-187
 // conv1 -> bn1 -> relu -> conv2): y is conv1's raw output, acc its fixed-point statistics (vqa_bn_acc_words(2, 64), filled by the launch
@@ -1036,7 +1075,7 @@ int vqa_conv3x3_c64p_bn(const void* y, const unsigned long long* acc, const floa
                         int B, int H, int W, int stats_mode, double count, float momentum, float eps, hipStream_t st) {
   if (!acc || !gamma || !beta || !coef_out || count <= 0) return VQA_EARG;
   C64Params p;
-  p.pre_mode = 2; p.pre_coef = nullptr;
+  p.pre_mode = 2; p.pre_coef = nullptr; p.addend = p.addmask = p.outmask = nullptr;
   p.pre = BnAcc{acc, gamma, beta, running_mean, running_var, num_batches_tracked, coef_out};
   p.pre_inv_count = 1.0 / count; p.pre_unbias = count > 1 ? count / (count - 1) : 1.0; p.pre_momentum = momentum; p.pre_eps = eps;
   return c64p_launch(p, y, w, out, stats, B, H, W, stats_mode, st);

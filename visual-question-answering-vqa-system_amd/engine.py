@@ -110,6 +110,7 @@ class HipEngine:
         # 12.31 forward only, 12.33 backward only (tools/ab_fusions.py, three alternations on one box; a second box: 12.73 -> 12.64)
         self.conv8p_n_multiple = 128
         self.conv8p_bwd_n_multiple = 128
+        self.use_c64p_epi = True                  # stage-1 conv1 data gradients (identity addend + masks) on the 8-wave patch kernel
         self.fuse_bn1_reduce = True               # bn1-backward column sums in the epilogue of conv2's data gradient (conv8p)
         self.use_conv8p_bwd = True                # ... also for the data gradients (they run beside the weight-gradient stream)
         self._accbuf = None
@@ -1107,6 +1108,9 @@ class HipEngine:
                 dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1, addend=dxd)
         elif c64_1 and not masked and outmask is None:
             dx, _, _ = K.conv3x3_c64(dy1, self._wflip(p + ".conv1.weight"), B, H, W, addend=dout, addmask=rec["out"])
+        elif self.use_c64p_epi and self._c64p_ok(B, H, W, Cout, Cin, 3, stride):
+            # stage 1: the patch kernel with the identity-path gradient and the ReLU masks in its per-tile epilogue (was the 128 x 64 igemm tile)
+            dx = K.conv3x3_c64p_epi(dy1, self._wflip(p + ".conv1.weight"), B, H, W, addend=dout, addmask=out_act, outmask=outmask)
         elif self.use_conv8p_bwd and stride == 1 and self._c8p_ok(B, H, W, Cout, Cin, 3, stride, 1, bwd=True):
             dx = K.conv8p(dy1, self.Wt(p + ".conv1.weight"), B, H, W, Cout, Cin, transposed=1, addend=dout, addmask=out_act, outmask=outmask)
         else:

@@ -163,6 +163,20 @@ def conv3x3_c64p(x, w, B, H, W, *, want_stats=False, stats_acc=None):
     return out, stats, nb
 
 
+def conv3x3_c64p_epi(x, w, B, H, W, *, addend, addmask=None, outmask=None):
+    """Data gradient of a 64 -> 64 channel 3x3/1 conv (w = the flipped pack) with the residual block's identity path in the epilogue:
+    (conv + addend * (addmask > 0)) * (outmask > 0) on the bf16 conv value (vqa_igemm's epilogue), 8-wave LDS-DMA patch kernel."""
+    out = torch.empty((B * H * W, 64), device=x.device, dtype=torch.bfloat16)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_conv3x3_c64p_epi", ptr(x), ptr(w), ptr(out), ptr(addend), ptr(addmask), ptr(outmask), B, H, W)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("conv3x3_c64p_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, (3 + (addmask is not None) + (outmask is not None)) * B * H * W * 64 * 2))
+    return out
+
+
 def conv3x3_c64p_bn(y, acc, bn, w, B, H, W, count, *, want_stats=False, stats_acc=None, momentum=0.1, eps=1e-5):
     """conv3x3_c64p(relu(BatchNorm_train(y))) without the normalised tensor: y = the previous conv's raw output, acc = its fixed-point
     statistics, bn = (gamma, beta, running_mean, running_var, num_batches_tracked).  Returns (out, stats | None, blocks, coef [4][64])."""
