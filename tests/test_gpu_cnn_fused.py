@@ -237,6 +237,10 @@ def test_bf16_step_with_and_without_the_round4_kernels():
     l_e, g_e = _bf16_step(cfg, sd, batch, use_c64p_epi=False)
     assert torch.equal(l_e, l_ref)
     assert float((g_e - g_ref).norm() / g_ref.norm()) < 0.15
+    # hoist_cross only moves launches between streams (layer 0's query projection beside the CNN, layer 1's K / V path forward and
+    # backward on the text stream): the same kernels on the same operands -> bit-identical, or an ordering event is missing
+    l_h, g_h = _bf16_step(cfg, sd, batch, hoist_cross=False)
+    assert torch.equal(l_h, l_ref) and torch.equal(g_h, g_ref)
     l_c, g_c = _bf16_step(cfg, sd, batch)                            # and the step itself is bit-reproducible
     assert torch.equal(l_c, l_ref) and torch.equal(g_c, g_ref)
 

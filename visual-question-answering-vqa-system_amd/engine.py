@@ -110,6 +110,7 @@ class HipEngine:
         # 12.31 forward only, 12.33 backward only (tools/ab_fusions.py, three alternations on one box; a second box: 12.73 -> 12.64)
         self.conv8p_n_multiple = 128
         self.conv8p_bwd_n_multiple = 128
+        self.hoist_cross = True                   # cross-attention: layer 0's query projection beside the CNN, layers >= 1's K / V path (fwd + bwd) on the text stream
         self.use_c64p_epi = True                  # stage-1 conv1 data gradients (identity addend + masks) on the 8-wave patch kernel
         self.fuse_bn1_reduce = True               # bn1-backward column sums in the epilogue of conv2's data gradient (conv8p)
         self.use_conv8p_bwd = True                # ... also for the data gradients (they run beside the weight-gradient stream)
@@ -566,6 +567,11 @@ class HipEngine:
                     xt = rec["out"]
                 text["enc"], enc_st = self._ln(xt, "text_encoder.final_norm")
                 tape["final_norm"] = dict(x=xt, st=enc_st)
+                if self.hoist_cross and cfg["num_cross_layers"] >= 1:
+                    # the first cross-attention layer's norm_query + W_q need the text features only: issued here, beside the CNN,
+                    # instead of behind the CNN on the fusion chain (the critical path between CNN forward and CNN backward)
+                    p0 = "fusion.cross_attention.layers.0"
+                    text["q0"] = self._cross_q_path(text["enc"], p0 + ".norm_query", p0 + ".cross_attention")
                 text["ev"] = torch.cuda.Event(); text["ev"].record()
 
         if self.mark: self.mark("forward: stem")
@@ -688,10 +694,28 @@ class HipEngine:
         q = enc
         tape["clayers"] = []
         probs_all = []
-        for l in range(cfg["num_cross_layers"]):
+        ncl = cfg["num_cross_layers"]
+        pre_kv = [None] * ncl
+        if self.hoist_cross and use_side and ncl > 1:
+            # every layer's K / V come from the SAME image tokens: layers >= 1 are projected on the (now idle) text stream while
+            # layer 0 runs here.  img lives on this stream and is read there; the results live there and are read here: both are
+            # ordered by the events below and kept alive by the tape (forward-only: freed after the last wait)
+            ev_img = torch.cuda.Event(); ev_img.record(main)
+            self.side.wait_event(ev_img)
+            with torch.cuda.stream(self.side):
+                for l in range(1, ncl):
+                    p = f"fusion.cross_attention.layers.{l}"
+                    pre_kv[l] = (self._cross_kv_path(img, p + ".norm_kv", p + ".cross_attention", d), torch.cuda.Event())
+                    pre_kv[l][1].record()
+        for l in range(ncl):
             p = f"fusion.cross_attention.layers.{l}"
+            pkv = None
+            if pre_kv[l] is not None:
+                pkv, ev_kv = pre_kv[l]
+                main.wait_event(ev_kv)
             rec = self._attn_block_fwd(q, img, None, p + ".norm_query", p + ".norm_kv", p + ".cross_attention", None, Bt, L, ntok,
-                                       heads, hd, pdrop, p + ".norm_ffn", p + ".ffn.0", p + ".ffn.3", self_attn=False)
+                                       heads, hd, pdrop, p + ".norm_ffn", p + ".ffn.0", p + ".ffn.3", self_attn=False,
+                                       pre_q=text.get("q0") if l == 0 else None, pre_kv=pkv)
             tape["clayers"].append(rec)
             probs_all.append(rec["probs"])
             q = rec["out"]
@@ -736,27 +760,43 @@ class HipEngine:
             tape = None
         return logits_f, aux, tape
 
-    def _attn_block_fwd(self, q_in, kv_in, _unused, norm_q, norm_kv, attn, kmask, B, Lq, Lk, heads, hd, p, norm_f, fc1, fc2, self_attn):
+    def _cross_q_path(self, q_in, norm_q, attn):
+        """norm_query + W_q of a cross-attention layer (cross_attention.py:286 and the query projection inside CrossAttention): needs
+        the query stream only."""
+        nq, stq = self._ln(q_in, norm_q)
+        return nq, stq, self._lin(nq, attn + ".W_q.weight")
+
+    def _cross_kv_path(self, kv_in, norm_kv, attn, d):
+        """norm_kv + W_k | W_v of a cross-attention layer (cross_attention.py:287): needs the image tokens only -- the same tensor for
+        every layer of StackedCrossAttention (cross_attention.py:357-361), so layers >= 1 do not sit on the query chain."""
+        nkv, stkv = self._ln(kv_in, norm_kv)
+        wk, wv = attn + ".W_k.weight", attn + ".W_v.weight"
+        if self._adjacent([wk, wv]):
+            kv = self._lin_multi(nkv, [wk, wv])
+            return nkv, stkv, kv, kv[:, d:], 2 * d, True
+        return nkv, stkv, self._lin(nkv, wk), self._lin(nkv, wv), d, False
+
+    def _attn_block_fwd(self, q_in, kv_in, _unused, norm_q, norm_kv, attn, kmask, B, Lq, Lk, heads, hd, p, norm_f, fc1, fc2, self_attn,
+                        pre_q=None, pre_kv=None):
         """pre-norm attention + FFN block (TransformerEncoderLayer.forward text_encoder.py:373-399 and
-        MultiHeadCrossAttention.forward cross_attention.py:285-299)."""
+        MultiHeadCrossAttention.forward cross_attention.py:285-299).  pre_q / pre_kv: the results of _cross_q_path / _cross_kv_path when
+        the caller issued them earlier (on another stream, already joined)."""
         T = self.dtype
         d = heads * hd
-        nq, stq = self._ln(q_in, norm_q)
-        if self_attn:
-            nkv, stkv = nq, None
-        else:
-            nkv, stkv = self._ln(kv_in, norm_kv)
         wq, wk, wv = attn + ".W_q.weight", attn + ".W_k.weight", attn + ".W_v.weight"
-        fused = self._adjacent([wq, wk, wv]) if self_attn else self._adjacent([wk, wv])
-        if fused and self_attn:                       # one [M][3d] GEMM; Q/K/V are column slices (row stride 3d)
-            qkv = self._lin_multi(nq, [wq, wk, wv])
-            Q, Kt, V, ldq, ldkv = qkv, qkv[:, d:], qkv[:, 2 * d:], 3 * d, 3 * d
-        elif fused:
-            Q = self._lin(nq, wq)
-            kv = self._lin_multi(nkv, [wk, wv])
-            Kt, V, ldq, ldkv = kv, kv[:, d:], d, 2 * d
+        if self_attn:
+            nq, stq = self._ln(q_in, norm_q)
+            nkv, stkv = nq, None
+            fused = self._adjacent([wq, wk, wv])
+            if fused:                                 # one [M][3d] GEMM; Q/K/V are column slices (row stride 3d)
+                qkv = self._lin_multi(nq, [wq, wk, wv])
+                Q, Kt, V, ldq, ldkv = qkv, qkv[:, d:], qkv[:, 2 * d:], 3 * d, 3 * d
+            else:
+                Q, Kt, V, ldq, ldkv = self._lin(nq, wq), self._lin(nkv, wk), self._lin(nkv, wv), d, d
         else:
-            Q, Kt, V, ldq, ldkv = self._lin(nq, wq), self._lin(nkv, wk), self._lin(nkv, wv), d, d
+            nq, stq, Q = pre_q if pre_q is not None else self._cross_q_path(q_in, norm_q, attn)
+            nkv, stkv, Kt, V, ldkv, fused = pre_kv if pre_kv is not None else self._cross_kv_path(kv_in, norm_kv, attn, d)
+            ldq = d
         probs = torch.empty((B, heads, Lq, Lk), device=Q.device, dtype=torch.float32)
         ctx = torch.empty((B * Lq, d), device=Q.device, dtype=T)
         sa = self._seed()
@@ -777,8 +817,11 @@ class HipEngine:
                     x1=x1, nf=nf, stf=stf, h=h, s1=s1, s2=s2, out=out, p=p, norm_q=norm_q, norm_kv=norm_kv, attn=attn, norm_f=norm_f,
                     fc1=fc1, fc2=fc2, self_attn=self_attn, B=B, Lq=Lq, Lk=Lk, heads=heads, hd=hd)
 
-    def _attn_block_bwd(self, rec, dout, G, dkv_addend=None):
-        """Returns (d q_in, d kv_in) ; for self-attention d kv_in is folded into d q_in."""
+    def _attn_block_bwd(self, rec, dout, G, dkv_addend=None, kv_side=False, addend_event=None):
+        """Returns (d q_in, d kv_in, event) ; for self-attention d kv_in is folded into d q_in.
+        kv_side: the K / V projection's data gradient and norm_kv's backward (they only feed the image-token gradient, which the query
+        chain of the remaining layers does not need) run on the text stream; `event` then marks d kv_in.  addend_event: the event of
+        the dkv_addend handed in by such a layer."""
         T = self.dtype
         p, B, Lq, Lk, heads, hd = rec["p"], rec["B"], rec["Lq"], rec["Lk"], rec["heads"], rec["hd"]
         d = heads * hd
@@ -816,16 +859,37 @@ class HipEngine:
                 dnq = self._lin_bwd(dK, rec["nkv"], wk, G, addend=dnq)
                 dnq = self._lin_bwd(dV, rec["nkv"], wv, G, addend=dnq)
             dq_in = self._ln_bwd(dnq, rec["q_in"], rec["norm_q"], rec["stq"], G, addend=dx1)
-            return dq_in, None
+            return dq_in, None, None
         dnq = self._lin_bwd(dQ, rec["nq"], wq, G)
+        main = torch.cuda.current_stream()
+        if kv_side and fused:
+            # the weight gradient is queued HERE (its operands dkv / nkv are this stream's; the queue is flushed on this stream) ...
+            e0 = self.E[wk]
+            Kin, N2 = e0.shape[1], 2 * d
+            self._wgrad_linear(dkv, rec["nkv"], G[e0.offset: e0.offset + N2 * Kin].view(N2, Kin), dkv.shape[0], N2, Kin)
+            wt = self._packT(wk + ".multiT2", [(e0.offset, N2, 1, Kin, 0, False)], Kin, N2)
+            ev = torch.cuda.Event(); ev.record(main)
+            self.side.wait_event(ev)
+            self._keep.append(dkv)                    # allocated here, read there
+            with torch.cuda.stream(self.side):        # ... the data gradient and the LayerNorm backward over the 49-token rows run there
+                dnkv, _, _ = K.igemm(dkv, wt, dkv.shape[0], Kin, N2, K.linear_geom(dkv.shape[0], N2), dtype=self.dtype)
+                if addend_event is not None:
+                    self.side.wait_event(addend_event)
+                dkv_in = self._ln_bwd(dnkv, rec["kv_in"], rec["norm_kv"], rec["stkv"], G, addend=dkv_addend)
+                ev_kv = torch.cuda.Event(); ev_kv.record()
+            self._keep.extend([dnkv, dkv_in])         # allocated there, read here (as the next layer's addend): alive until the join
+            dq_in = self._ln_bwd(dnq, rec["q_in"], rec["norm_q"], rec["stq"], G, addend=dx1)
+            return dq_in, dkv_in, ev_kv
         if fused:
             dnkv = self._lin_multi_bwd(dkv, rec["nkv"], [wk, wv], G)
         else:
             dnkv = self._lin_bwd(dK, rec["nkv"], wk, G)
             dnkv = self._lin_bwd(dV, rec["nkv"], wv, G, addend=dnkv)
         dq_in = self._ln_bwd(dnq, rec["q_in"], rec["norm_q"], rec["stq"], G, addend=dx1)
+        if addend_event is not None:
+            main.wait_event(addend_event)             # (also orders the parameter-gradient folds queued by that layer before seg())
         dkv_in = self._ln_bwd(dnkv, rec["kv_in"], rec["norm_kv"], rec["stkv"], G, addend=dkv_addend)
-        return dq_in, dkv_in
+        return dq_in, dkv_in, None
 
     # ------------------------------------------------------------------ backward
     def backward(self, tape: dict, dlogits: torch.Tensor, G: torch.Tensor, on_segment: Optional[Callable[[str], None]] = None):
@@ -885,9 +949,13 @@ class HipEngine:
         denc = torch.empty_like(pr["enc"])
         call("vqa_masked_pool_bwd", dt(T), ptr(dcat), 2 * d, d, ptr(pr["maskf"]), None, ptr(denc), B, L, d)
         # ---- cross-attention layers (reverse); image-token gradient accumulates across layers
-        dimg = None
-        for rec in reversed(tape["clayers"]):
-            dq, dimg = self._attn_block_bwd(rec, dq, G, dkv_addend=dimg)
+        dimg, ev_img = None, None
+        side_ok = self.hoist_cross and self.two_streams and self.side is not None
+        for li in range(len(tape["clayers"]) - 1, -1, -1):
+            dq, dimg, ev_img = self._attn_block_bwd(tape["clayers"][li], dq, G, dkv_addend=dimg, kv_side=side_ok and li >= 1,
+                                                    addend_event=ev_img)
+        if ev_img is not None:                                    # (a single layer never takes the side path; kept for safety)
+            torch.cuda.current_stream().wait_event(ev_img)
         # dq is now the gradient wrt text features through the query path
         call("vqa_add", dt(T), ptr(denc), ptr(dq), ptr(denc), denc.numel())
         # ---- projector
@@ -909,7 +977,7 @@ class HipEngine:
             fn = tape["final_norm"]
             dx = self._ln_bwd(denc, fn["x"], "text_encoder.final_norm", fn["st"], G)
             for rec in reversed(tape["tlayers"]):
-                dx, _ = self._attn_block_bwd(rec, dx, G)
+                dx, _, _ = self._attn_block_bwd(rec, dx, G)
             em = tape["embed"]; emb_e = self.E["text_encoder.token_embedding.weight"]
             call("vqa_embed_bwd", dt(T), ptr(em["ids"]), ptr(dx), ptr(self._gslice(G, emb_e.name)), dx.shape[0], d, emb_e.shape[0],
                  math.sqrt(d), float(em["p"]), em["seed"])
