@@ -64,6 +64,10 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
 int vqa_conv3x3_c64p_blocks(int B, int H, int W);
 /* ... and the data gradient of a residual block's conv1 (w = flipped + transposed pack) with the identity path in the epilogue:
  * out = (conv + addend * (addmask > 0)) * (outmask > 0) on the bf16 conv value, as vqa_igemm / vqa_conv8p; addend required, masks or NULL. */
+/* ... and conv2's data gradient that also leaves bn1's BatchNorm-backward column sums (as vqa_conv8p's bn_y / bn_coef / bn_facc): the
+ * stored tile is the gradient entering relu(BatchNorm(bn_y)); bn_coef = coef[4][64], bn_facc = zeroed vqa_bn_acc_words(3, 64). */
+int vqa_conv3x3_c64p_bnred(const void* x, const void* w, void* out, const void* bn_y, const float* bn_coef, unsigned long long* bn_facc,
+                           int B, int H, int W, hipStream_t stream);
 int vqa_conv3x3_c64p_epi(const void* x, const void* w, void* out, const void* addend, const void* addmask, const void* outmask,
                          int B, int H, int W, hipStream_t stream);
 int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W,

@@ -368,6 +368,25 @@ def test_conv3x3_c64_dma_patch_kernel(case):
         assert torch.equal(d2.float(), e), kw.keys()
     with pytest.raises(RuntimeError):
         sub("_lib").call("vqa_conv3x3_c64p_epi", dy.data_ptr(), wflip.data_ptr(), dx.data_ptr(), None, None, None, B, H, W)
+    # conv2's data gradient that also leaves bn1's backward column sums: same output bits; sums = vqa_bn_bwd_reduce(self_mask) over (dx, y)
+    L = sub("_lib")
+    yv = add                                                                      # any bf16 tensor serves as the BatchNorm input
+    coef = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1,
+                        torch.rand(64, generator=g) + 0.5]).to(DEV).contiguous()
+    words = L.count("vqa_bn_acc_words", 3, 64)
+    facc, fref = torch.zeros(words, device=DEV, dtype=torch.int64), torch.zeros(words, device=DEV, dtype=torch.int64)
+    d3 = K.conv3x3_c64p_bnred(nhwc(dy), wflip, B, H, W, yv, coef, facc)
+    assert torch.equal(d3, dx)
+    L.call("vqa_bn_bwd_reduce", L.dt(dtype), dx.data_ptr(), None, yv.data_ptr(), coef.data_ptr(), None, None, fref.data_ptr(), B * H * W, 64, 1, 1)
+    def dec(acc, R=8, Kk=3, C=64):
+        n = R * Kk * C
+        return acc[:n].view(R, Kk, C).sum(0).double() / 16.0 + acc[n + 1: 2 * n + 1].view(R, Kk, C).sum(0).double() / float(1 << 50), int(acc[n])
+    (s3, f3), (s4, f4) = dec(facc), dec(fref)
+    gm = dx.double() * ((yv.double() * coef[0].double() + coef[1].double()) > 0)
+    scale = max(1.0, float(gm.abs().sum(0).max()))
+    assert f3 == 0 and f4 == 0 and s3[2].abs().max().item() == 0
+    assert (s3[0] - s4[0]).abs().max().item() <= 2e-5 * scale and (s3[1] - s4[1]).abs().max().item() <= 2e-5 * scale
+    assert (s3[0] - gm.sum(0)).abs().max().item() <= 1e-3 * scale
     assert K.c64p_blocks(2, 10, 10) == 0 and K.c64p_blocks(2, 6, 16) == 0 and K.c64p_blocks(2, 8, 128) == 0   # refused, not mangled
 
 

@@ -10,6 +10,9 @@ data = bench.synth_batch(512, torch.device("cuda", 0), 1234)
 CASES = [("default", {}), ("cross-attention q / kv paths not hoisted", dict(hoist_cross=False)), ("no c64p epilogue variant (igemm 128x64)", dict(use_c64p_epi=False)), ("no bn1 reduce in the dgrad epilogue", dict(fuse_bn1_reduce=False)), ("conv8p not for stage 2 (igemm there)", dict(conv8p_n_multiple=256, conv8p_bwd_n_multiple=256)), ("no conv8p (igemm 128x128)", dict(use_conv8p=False)), ("conv8p forward only", dict(use_conv8p_bwd=False)), ("no fuse_bn_conv (a1 stored)", dict(fuse_bn_conv=False)), ("no bn_finalize fusion", dict(fuse_bn_finalize=False)), ("no se_pool", dict(fuse_se_pool=False)),
          ("no se_bnred", dict(fuse_se_bnred=False)), ("none of the three", dict(fuse_se_pool=False, fuse_se_bnred=False, fuse_bn_finalize=False))]
 NC = int(os.environ.get("AB_CASES", "4"))
+if os.environ.get("AB_ONLY"):          # e.g. AB_ONLY=0,3: the cases with these indices
+    CASES = [CASES[int(i)] for i in os.environ["AB_ONLY"].split(",")]
+    NC = len(CASES)
 for rep in range(int(os.environ.get("AB_REPS", "2"))):
     for tag, kw in CASES[:NC]:
         model = M.VQAModel(compute_dtype="bf16", seed=1234).to("cuda").train()

@@ -34,6 +34,7 @@ SIGNATURES = {
     "vqa_conv3x3_c64p_blocks": [I, I, I],
     "vqa_conv3x3_c64p": [P, P, P, P, I, I, I, I, P],
     "vqa_conv3x3_c64p_epi": [P, P, P, P, P, P, I, I, I, P],
+    "vqa_conv3x3_c64p_bnred": [P, P, P, P, P, P, I, I, I, P],
     "vqa_conv3x3_c64p_bn": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, D, F, F, P],
     "vqa_wgrad3x3_c64_bn_ok": [I, I, I],
     "vqa_wgrad3x3_c64_bn": [P, P, P, P, I, I, I, P, LL, P],

@@ -28,6 +28,10 @@ __device__ __forceinline__ int patch_off(int prow, int pcol, int chunk, int PWc)
 struct C64Params {
   const bf16_t* x; const bf16_t* w; bf16_t* out; float* stats; const bf16_t* addend; const bf16_t* addmask;
   const bf16_t* outmask;     // 8-wave kernel, EPI variant: out = (conv + addend * (addmask > 0)) * (outmask > 0)  (addmask, outmask optional)
+  // 8-wave kernel, BNRED variant: the stored tile is the gradient entering relu(BatchNorm(bn_y)) (conv2's data gradient da1 entering
+  // bn1): its BatchNorm-backward column sums  sum g | sum g * xhat,  g = out * [bn_y * scale + shift > 0]  go to bn_facc
+  // (vqa_bn_acc_words(3, 64), the layout vqa_bn_bwd_apply_acc reads) and the vqa_bn_bwd_reduce pass over (out, bn_y) is skipped
+  const bf16_t* bn_y; const float* bn_coef; unsigned long long* bn_facc;
   int stats_mode;            // 1: stats is a fixed-point accumulator u64 [vqa_bn_acc_words(2, 64)] (common.h acc_add_fixed), not a per-workgroup slab
   int B, H, W; unsigned x_bytes;
   int dbg;                        // VQA_C64P_DBG (measurement only, wrong results): bit 0 no epilogue, bit 1 no MFMA loop, bit 2 no in-loop DMA
@@ -258,15 +262,20 @@ __device__ __forceinline__ void dma16_c64(i32x4_c64 rs, unsigned lds_addr, int v
 // (engine._block_bwd; vqa_igemm's epilogue on the bf16 conv value, bit for bit).  A lane's three 16-byte epilogue loads are issued at
 // the top of its tile, ~36 MFMAs ahead of their use; the waits the compiler counts for them also cover the (older, hidden) DMA pieces
 // of the prefetch, which at one tile's distance have landed.  No statistics in this variant: their 16 registers hold the loads.
-template <int RBP, bool EPI>
+// BNRED (round 4, MODE 2): conv2's data gradient also leaves bn1's backward column sums (C64Params).  A lane owns 8 channels of one
+// pixel per tile: it loads its 16 bytes of bn_y at the top of the tile, reads its channels' scale | shift | mean from LDS at the
+// epilogue (no registers left to keep them: 245 of 256 are taken), masks the bf16 value it stores and adds g, g * (y - mean) to
+// the 16 registers the forward variant uses for sum / sum of squares; invstd is applied once, in the final fold.
+template <int RBP, int MODE>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
+  constexpr bool EPI = MODE == 1, BNRED = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PWc = p.W + 2;
   const int patch_elems = (RBP + 2) * PWc * CH;
   bf16_t* patch0 = reinterpret_cast<bf16_t*>(smem);
   bf16_t* patch1 = patch0 + patch_elems;
   float* red = reinterpret_cast<float*>(patch1 + patch_elems);  // [4 m-waves][64][2]
-  float* cf = red + 4 * 64 * 2;                                 // [2][64] scale | shift of the input's BatchNorm (pre_mode != 0)
+  float* cf = red + 4 * 64 * 2;                                 // [2][64] scale | shift of the input's BatchNorm (pre_mode != 0); BNRED: coef [4][64]
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wm = wave >> 1;                    // wave owns channels [32*wn, 32*wn+32), m tiles wm, wm+4, ...
@@ -316,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
   int blk = blockIdx.x, buf = 0;
   if (blk < nblocks) issue_patch(blk, 0);
   if (p.pre_mode) pre_bn_coef(p.pre_mode, p.pre_coef, p.pre, p.pre_inv_count, p.pre_unbias, p.pre_momentum, p.pre_eps, cf, tid);   // (under the first DMA)
+  if (BNRED && tid < 256) cf[tid] = p.bn_coef[tid];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (; blk < nblocks; blk += gridDim.x, buf ^= 1) {
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
         if (p.addmask) e_m = ldg16(p.addmask + ooff);
         if (p.outmask) e_o = ldg16(p.outmask + ooff);
       }
+      if (BNRED) e_a = ldg16(p.bn_y + ooff);
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int kk = 0; kk < 18; ++kk) {
@@ -385,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) { if (EPI) break; const float v = acc[nt][rr]; ssum[4 * nt + rr] += v; ssq[4 * nt + rr] += v * v; }
+        for (int rr = 0; rr < 4; ++rr) { if (MODE) break; const float v = acc[nt][rr]; ssum[4 * nt + rr] += v; ssq[4 * nt + rr] += v * v; }
         o[2 * nt] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){acc[nt][0], acc[nt][1]}, bf16x2_t));
         o[2 * nt + 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){acc[nt][2], acc[nt][3]}, bf16x2_t));
       }
@@ -404,6 +415,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
         }
         o = v.raw;
       }
+      if (BNRED) {                                                  // per element as bn_bwd_reduce_kernel<SELF>: the STORED bf16 value, the recomputed mask
+        const int c0 = wn * 32 + 8 * g;
+        Vec16<bf16_t> v; v.raw = o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(cf + c0 + 4 * h), sh = *reinterpret_cast<const f32x4*>(cf + 64 + c0 + 4 * h),
+                      mu = *reinterpret_cast<const f32x4*>(cf + 128 + c0 + 4 * h);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float yj = e_a.get(4 * h + j);
+            float gj = v.get(4 * h + j);
+            if (!(yj * sc[j] + sh[j] > 0.f)) gj = 0.f;
+            ssum[4 * h + j] += gj; ssq[4 * h + j] += gj * (yj - mu[j]);
+          }
+        }
+      }
       (void)orow_c; (void)ow_c;
       *reinterpret_cast<u32x4*>(p.out + ooff) = o;
     }
@@ -414,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  if (!EPI && p.stats) {
+  if (!EPI && (p.stats || BNRED)) {
     // fold the 16 pixels (lanes li) of each channel group, then the 4 m-waves through LDS, in a fixed order
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -432,7 +459,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { s += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
-      if (p.stats_mode) {
+      if (BNRED) {                                                  // K = 3 layout of the BatchNorm-backward accumulators (row 2: the shortcut's, unused)
+        const int R = acc_replicas(64);
+        const size_t fr = (size_t)(blockIdx.x % R) * 192;
+        acc_add_fixed(p.bn_facc, (size_t)R * 192, fr + tid, s);
+        acc_add_fixed(p.bn_facc, (size_t)R * 192, fr + 64 + tid, q * cf[192 + tid]);
+      } else if (p.stats_mode) {
         const int R = acc_replicas(64);
         unsigned long long* fa = reinterpret_cast<unsigned long long*>(p.stats);
         const size_t fr = (size_t)(blockIdx.x % R) * 128;
@@ -1002,7 +1034,7 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
   if (!x || !w || !out || grid <= 0) return VQA_EARG;
   C64Params p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
-  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.outmask = nullptr; p.B = B; p.H = H; p.W = W; p.dbg = 0; p.stats_mode = 0; p.pre_mode = 0; p.pre_coef = nullptr;
+  p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.outmask = nullptr; p.bn_y = nullptr; p.bn_coef = nullptr; p.bn_facc = nullptr; p.B = B; p.H = H; p.W = W; p.dbg = 0; p.stats_mode = 0; p.pre_mode = 0; p.pre_coef = nullptr;
   const size_t xb = (size_t)B * H * W * CH * 2;
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb;
@@ -1038,21 +1070,34 @@ static int c64p_launch(C64Params& p, const void* x, const void* w, void* out, fl
   if (xb >= 0x7fffffffull) return VQA_EARG;
   p.x_bytes = (unsigned)xb;
   const int rbp = c64p_rows(H, W);
-  const size_t shm = (size_t)2 * (rbp + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4 + 2 * 64 * 4;
+  const size_t shm = (size_t)2 * (rbp + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4 + 4 * 64 * 4;
   static size_t attr8 = 0, attr4 = 0;
-  static size_t attr[4] = {0, 0, 0, 0};
+  static size_t attr[6] = {0, 0, 0, 0, 0, 0};
 #define C64P_GO(RB, EP, SLOT) do { auto kfn = conv3x3_c64p_kernel<RB, EP>; \
     if (shm > attr[SLOT]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr[SLOT] = shm; } \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), shm, st, p); } while (0)
-  if (p.addend) { if (rbp == 8) C64P_GO(8, true, 2); else C64P_GO(4, true, 3); }
-  else { if (rbp == 8) C64P_GO(8, false, 0); else C64P_GO(4, false, 1); }
+  if (p.addend && p.bn_y) return VQA_EARG;
+  if (p.addend) { if (rbp == 8) C64P_GO(8, 1, 2); else C64P_GO(4, 1, 3); }
+  else if (p.bn_y) { if (rbp == 8) C64P_GO(8, 2, 4); else C64P_GO(4, 2, 5); }
+  else { if (rbp == 8) C64P_GO(8, 0, 0); else C64P_GO(4, 0, 1); }
 #undef C64P_GO
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int B, int H, int W, int stats_mode, hipStream_t st) {
   C64Params p;
-  p.pre_mode = 0; p.pre_coef = nullptr; p.addend = p.addmask = p.outmask = nullptr;
+  p.pre_mode = 0; p.pre_coef = nullptr; p.addend = p.addmask = p.outmask = nullptr; p.bn_y = nullptr; p.bn_coef = nullptr; p.bn_facc = nullptr;
   return c64p_launch(p, x, w, out, stats, B, H, W, stats_mode, st);
+}
+// conv2's data gradient da1 = conv(dy2, flipped pack) that also leaves bn1's BatchNorm-backward column sums (C64Params, BNRED): bn_y = conv1's
+// raw output y1, bn_coef = bn1's coef[4][64] (scale | shift | mean | invstd), bn_facc = a zeroed vqa_bn_acc_words(3, 64) accumulator.
+int vqa_conv3x3_c64p_bnred(const void* x, const void* w, void* out, const void* bn_y, const float* bn_coef, unsigned long long* bn_facc,
+                           int B, int H, int W, hipStream_t st) {
+  if (!bn_y || !bn_coef || !bn_facc) return VQA_EARG;
+  if ((size_t)vqa_conv3x3_c64p_blocks(B, H, W) > (size_t)VQA_ACC_MAX_PARTS) return VQA_EARG;
+  C64Params p;
+  p.pre_mode = 0; p.pre_coef = nullptr; p.addend = p.addmask = p.outmask = nullptr;
+  p.bn_y = (const bf16_t*)bn_y; p.bn_coef = bn_coef; p.bn_facc = bn_facc;
+  return c64p_launch(p, x, w, out, nullptr, B, H, W, 0, st);
 }
 // The data gradient of a residual block's conv1 (w = the flipped + transposed pack) with the block's identity path in the epilogue:
 // out = (conv + addend * (addmask > 0)) * (outmask > 0) on the bf16 conv value, the epilogue of vqa_igemm / vqa_conv8p.  addend required;
@@ -1063,6 +1108,7 @@ int vqa_conv3x3_c64p_epi(const void* x, const void* w, void* out, const void* ad
   C64Params p;
   p.pre_mode = 0; p.pre_coef = nullptr;
   p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.outmask = (const bf16_t*)outmask;
+  p.bn_y = nullptr; p.bn_coef = nullptr; p.bn_facc = nullptr;
   return c64p_launch(p, x, w, out, nullptr, B, H, W, 0, st);
 }
 // The same conv applied to relu(BatchNorm(y)) in TRAINING mode, the normalised tensor never materialised (models/cnn_backbone.py:182-187
@@ -1075,7 +1121,7 @@ int vqa_conv3x3_c64p_bn(const void* y, const unsigned long long* acc, const floa
                         int B, int H, int W, int stats_mode, double count, float momentum, float eps, hipStream_t st) {
   if (!acc || !gamma || !beta || !coef_out || count <= 0) return VQA_EARG;
   C64Params p;
-  p.pre_mode = 2; p.pre_coef = nullptr; p.addend = p.addmask = p.outmask = nullptr;
+  p.pre_mode = 2; p.pre_coef = nullptr; p.addend = p.addmask = p.outmask = nullptr; p.bn_y = nullptr; p.bn_coef = nullptr; p.bn_facc = nullptr;
   p.pre = BnAcc{acc, gamma, beta, running_mean, running_var, num_batches_tracked, coef_out};
   p.pre_inv_count = 1.0 / count; p.pre_unbias = count > 1 ? count / (count - 1) : 1.0; p.pre_momentum = momentum; p.pre_eps = eps;
   return c64p_launch(p, y, w, out, stats, B, H, W, stats_mode, st);

@@ -112,7 +112,7 @@ class HipEngine:
         self.conv8p_bwd_n_multiple = 128
         self.hoist_cross = True                   # cross-attention: layer 0's query projection beside the CNN, layers >= 1's K / V path (fwd + bwd) on the text stream
         self.use_c64p_epi = True                  # stage-1 conv1 data gradients (identity addend + masks) on the 8-wave patch kernel
-        self.fuse_bn1_reduce = True               # bn1-backward column sums in the epilogue of conv2's data gradient (conv8p)
+        self.fuse_bn1_reduce = True               # bn1-backward column sums in the epilogue of conv2's data gradient (conv8p, stage 1: the patch kernel)
         self.use_conv8p_bwd = True                # ... also for the data gradients (they run beside the weight-gradient stream)
         self._accbuf = None
         self._accpos = 0
@@ -496,7 +496,8 @@ class HipEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, images: torch.Tensor, token_ids: torch.Tensor, maskf: Optional[torch.Tensor], training: bool,
-                want_aux: bool = False, need_tape: bool = True):
+                want_aux: bool = False, need_tape: bool = True, lowp_logits: bool = False):
+        """lowp_logits: return the logits in the compute dtype (the trainer's loss kernel reads bf16 and leaves the fp32 copy itself)."""
         cfg, T = self.cfg, self.dtype
         self._site = 0
         if training:
@@ -741,7 +742,7 @@ class HipEngine:
         h2 = self._lin(h1, c + ".3.weight", c + ".3.bias", relu=1, p=phead, seed=s2)
         logits = self._lin(h2, c + ".6.weight", c + ".6.bias")
         tape["head"] = dict(fused=fused, h1=h1, h2=h2, s1=s1, s2=s2, p=phead)
-        logits_f = logits.float() if T != torch.float32 else logits
+        logits_f = logits.float() if (T != torch.float32 and not lowp_logits) else logits
 
         aux = None
         if want_aux:
@@ -1136,7 +1137,10 @@ class HipEngine:
         else:
             self._off_path([dy2], lambda: K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T))
         slab1, nb1, facc1 = None, 0, None
-        if self._c64p_ok(B, Ho, Wo, Cout, Cout, 3, 1):
+        if self._c64p_ok(B, Ho, Wo, Cout, Cout, 3, 1) and bacc and self.fuse_bn1_reduce:
+            facc1 = self._acc(K.L.count("vqa_bn_acc_words", 3, Cout))      # (as below for conv8p: bn1's backward sums leave this launch)
+            da1 = K.conv3x3_c64p_bnred(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo, rec["y1"], rec["c1"], facc1)
+        elif self._c64p_ok(B, Ho, Wo, Cout, Cout, 3, 1):
             da1, _, _ = K.conv3x3_c64p(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)
         elif c64_2:
             da1, _, _ = K.conv3x3_c64(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo)

@@ -163,6 +163,20 @@ def conv3x3_c64p(x, w, B, H, W, *, want_stats=False, stats_acc=None):
     return out, stats, nb
 
 
+def conv3x3_c64p_bnred(x, w, B, H, W, bn_y, bn_coef, bn_facc):
+    """conv3x3_c64p (data gradient, w = the flipped pack) whose output is the gradient entering relu(BatchNorm(bn_y)): also adds that
+    BatchNorm's backward column sums (sum g | sum g * xhat, g = out * [bn_y * scale + shift > 0]) to the zeroed accumulator bn_facc."""
+    out = torch.empty((B * H * W, 64), device=x.device, dtype=torch.bfloat16)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_conv3x3_c64p_bnred", ptr(x), ptr(w), ptr(out), ptr(bn_y), ptr(bn_coef), ptr(bn_facc), B, H, W)
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("conv3x3_c64p_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 3 * B * H * W * 64 * 2))
+    return out
+
+
 def conv3x3_c64p_epi(x, w, B, H, W, *, addend, addmask=None, outmask=None):
     """Data gradient of a 64 -> 64 channel 3x3/1 conv (w = the flipped pack) with the residual block's identity path in the epilogue:
     (conv + addend * (addmask > 0)) * (outmask > 0) on the bf16 conv value (vqa_igemm's epilogue), 8-wave LDS-DMA patch kernel."""

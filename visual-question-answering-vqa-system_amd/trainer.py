@@ -189,12 +189,16 @@ class HipTrainer:
         if self._copy_sig is not None and eng.adamw_copy_target() is not None and self._copy_sig == self._param_sig():
             eng._wsrc_fresh = True                 # (one-shot, consumed by the begin_step of the forward below)
         maskf = None if attention_mask is None else attention_mask.contiguous().float()
-        logits_f, _, tape = eng.forward(images, token_ids, maskf, True, False, need_tape=True)
-        B, N = logits_f.shape
-        dlogits = torch.empty((B, N), device=images.device, dtype=torch.float32)
+        logits, _, tape = eng.forward(images, token_ids, maskf, True, False, need_tape=True, lowp_logits=True)
+        B, N = logits.shape
+        # the loss kernel reads the logits in the compute dtype, writes d logits in it and leaves the fp32 logits the caller gets:
+        # the same values as logits.float() -> loss -> d logits.to(bf16), two elementwise launches less between forward and backward
+        lowp = logits.dtype != torch.float32
+        logits_f = torch.empty((B, N), device=images.device, dtype=torch.float32) if lowp else logits
+        dlogits = torch.empty((B, N), device=images.device, dtype=logits.dtype)
         ce_ws = torch.empty((B,), device=images.device, dtype=torch.float32)
-        call("vqa_cross_entropy", 0, ptr(logits_f), ptr(targets), ptr(self.loss), ptr(dlogits), None, B, N, 1.0, ptr(self.bad_step),
-             ptr(ce_ws))                                   # per-row loss terms, folded in row order (bit-reproducible)
+        call("vqa_cross_entropy", dt(logits), ptr(logits), ptr(targets), ptr(self.loss), ptr(dlogits), ptr(logits_f) if lowp else None, B, N, 1.0,
+             ptr(self.bad_step), ptr(ce_ws))               # per-row loss terms, folded in row order (bit-reproducible)
         self.reducer.reduce_aux(self.bad_step)             # every rank must skip the update of a step ANY rank rejects
         if metrics is not None:
             metrics.update(logits_f, targets)
