@@ -87,6 +87,10 @@ int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stat
                const void* bn_y, const float* bn_coef, unsigned long long* bn_facc /* all or none: also the BatchNorm-backward column sums of the stored
                   tile as the gradient entering relu(BatchNorm(bn_y)): sum g | sum g*xhat, g = out * [bn_y*scale + shift > 0], into bn_facc
                   (vqa_bn_acc_words(3, N)); the caller then skips vqa_bn_bwd_reduce and runs vqa_bn_bwd_apply_acc on it */,
+               int bn_selfmask /* 1: as above (ReLU directly behind that BatchNorm, mask recomputed from bn_y); 0: g = out, the tile already carries
+                  its mask (outmask = the output of the block whose bn2 this is) */,
+               const void* bn_y2, const float* bn_coef2 /* both or none, bn_selfmask 0 only: the 1x1 shortcut's BatchNorm sharing g -> third row
+                  sum g*xhat(bn_y2), as vqa_bn_bwd_reduce with y2 / coef2 */,
                int B, int H, int W, int C, int N, int transposed, int stride /* 1, or 2: forward 3x3 / 2 convs (H, W = input map) */, hipStream_t stream);
 /* Round 4 -- training-mode "Conv3x3 + BN + ReLU" without the normalised tensor (models/cnn_backbone.py:182-187: conv1 -> bn1 -> relu ->
  * conv2 at 64 channels).  vqa_conv3x3_c64p_bn is vqa_conv3x3_c64p applied to relu(BatchNorm(y)): y = the previous conv's raw output,

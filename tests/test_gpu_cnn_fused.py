@@ -232,6 +232,11 @@ def test_bf16_step_with_and_without_the_round4_kernels():
     l_d, g_d = _bf16_step(cfg, sd, batch, fuse_bn1_reduce=False)
     assert torch.equal(l_d, l_ref)
     assert float((g_d - g_ref).norm() / g_ref.norm()) < 0.03
+    # fuse_hand_reduce: the first block's bn2 (+ shortcut BatchNorm) backward sums taken in the epilogue of the second block's conv1 data
+    # gradient (stages 2-4) instead of a bn_bwd_reduce pass: forward untouched, sums equal up to the grouping of fp32 partials
+    l_f, g_f = _bf16_step(cfg, sd, batch, fuse_hand_reduce=True)      # (off by default: measured neutral, engine.py)
+    assert torch.equal(l_f, l_ref)
+    assert float((g_f - g_ref).norm() / g_ref.norm()) < 0.03
     # use_c64p_epi: stage 1's conv1 data gradients on the patch kernel instead of the 128 x 64 igemm tile (other summation order, like
     # use_conv8p but backward only)
     l_e, g_e = _bf16_step(cfg, sd, batch, use_c64p_epi=False)

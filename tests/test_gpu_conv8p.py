@@ -122,8 +122,32 @@ def test_conv8p_matches_aten(B, H, W, C, N, transposed):
                 scale = max(1.0, float(gm.abs().sum(0).max()))
                 assert (s4[k] - s5[k]).abs().max().item() <= 2e-5 * scale and (s4[k] - e).abs().max().item() <= 1e-3 * scale, (k, kw.keys())
             assert s4[2].abs().max().item() == 0
+        # ... and for an already masked tile (the gradient handed to the previous block: outmask = its output) with that block's shortcut
+        # BatchNorm sharing the gradient: g = the stored value, three rows (sum g | sum g xhat(y) | sum g xhat(y2)) = vqa_bn_bwd_reduce(y2 =, coef2 =)
+        y2 = torch.randn(B * H * W, N, generator=g).to(DEV, bf)
+        coef2 = torch.stack([torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.3, torch.randn(N, generator=g) * 0.1,
+                             torch.rand(N, generator=g) + 0.5]).to(DEV).contiguous()
+        for dual in (False, True):
+            facc = torch.zeros(words, device=DEV, dtype=torch.int64)
+            o6 = K.conv8p(x, wt.view(N, 9 * C), B, H, W, C, N, transposed=1, addend=add, outmask=om,
+                          bnred=(y, coef, facc, False, y2 if dual else None, coef2 if dual else None))
+            o7 = K.conv8p(x, wt.view(N, 9 * C), B, H, W, C, N, transposed=1, addend=add, outmask=om)
+            assert torch.equal(o6, o7)
+            R = max(1, min(8, 512 // N))
+            s6, f6 = _acc_decode(facc, R, 3, N)
+            gd = o7.double()
+            e = [gd.sum(0), (gd * (y.double() - coef[2].double()) * coef[3].double()).sum(0),
+                 (gd * (y2.double() - coef2[2].double()) * coef2[3].double()).sum(0) if dual else torch.zeros(N, dtype=torch.float64, device=DEV)]
+            scale = max(1.0, float(gd.abs().sum(0).max()))
+            assert f6 == 0
+            for k in range(3):
+                assert (s6[k] - e[k]).abs().max().item() <= 1e-3 * scale, (dual, k)
+            if not dual:
+                assert s6[2].abs().max().item() == 0
+        with pytest.raises(RuntimeError):                                        # a second BatchNorm only for an already masked tile
+            K.conv8p(x, wt.view(N, 9 * C), B, H, W, C, N, transposed=1, bnred=(y, coef, torch.zeros(words, device=DEV, dtype=torch.int64), True, y2, coef2))
         with pytest.raises(RuntimeError):                                        # all three or none
-            L.call("vqa_conv8p", x.data_ptr(), wt.data_ptr(), out.data_ptr(), None, None, None, None, y.data_ptr(), None, None, B, H, W, C, N, 1, 1)
+            L.call("vqa_conv8p", x.data_ptr(), wt.data_ptr(), out.data_ptr(), None, None, None, None, y.data_ptr(), None, None, 1, None, None, B, H, W, C, N, 1, 1)
     if not transposed:
         R = max(1, min(8, 512 // N))
         sums, flag = _acc_decode(acc, R, 2, N)

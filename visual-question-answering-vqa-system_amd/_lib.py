@@ -19,7 +19,7 @@ P, I, F, D, LL, ULL = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong, 
 SIGNATURES = {
     "vqa_gemm8p": [P, P, P, I, I, I, P],
     "vqa_conv8p_ok": [I, I, I, I, I],
-    "vqa_conv8p": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "vqa_conv8p": [P, P, P, P, P, P, P, P, P, P, I, P, P, I, I, I, I, I, I, I, P],
     "vqa_igemm_mtiles": [I, I, I],
     "vqa_igemm_variant": [I] * 15,
     "vqa_igemm": [I, I, P, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, I, P],

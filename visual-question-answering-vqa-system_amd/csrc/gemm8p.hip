@@ -213,6 +213,10 @@ struct C8Params {
   // gradient da1 of conv2 entering bn1 --: g = out * [bn_y * scale + shift > 0],  sum g | sum g * xhat(bn_y)  -> bn_facc (vqa_bn_acc_words(3, N),
   // the layout vqa_bn_bwd_apply_acc reads); the standalone vqa_bn_bwd_reduce pass over (out, bn_y) is then skipped by the caller
   const bf16_t* bn_y; const float* bn_coef; unsigned long long* bn_facc;
+  // bn_selfmask = 0: the tile is the gradient entering a BatchNorm whose ReLU mask the epilogue has already applied (outmask = the block
+  // output: the gradient handed to the previous residual block, entering ITS bn2): g = out.  bn_y2 / bn_coef2: that block's 1x1-shortcut
+  // BatchNorm sharing g -> the third row, sum g * xhat(bn_y2) (what bn_bwd_reduce_kernel<false, DUAL> leaves)
+  int bn_selfmask; const bf16_t* bn_y2; const float* bn_coef2;
   int M, N, K, B, H, W, C, transposed, rpt, tiles_n, ntiles, cpk_shift;
   int Ho, Wo, stride;                 // output map (= H, W for stride 1); forward convs also run with stride 2 (the stage-entry 3x3 / 2 convs)
   unsigned x_bytes, w_bytes;
@@ -417,12 +421,14 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   const int rows = min(p.rpt, p.M - m0);
   const bool bnred = p.bn_y != nullptr;
   const bool fused = p.addend != nullptr || p.outmask != nullptr || bnred;
-  float bsc[8], bsh[8], bmu[8], biv[8];
+  const bool dual = bnred && p.bn_y2 != nullptr;
+  float bsc[8], bsh[8], bmu[8], biv[8], bmu2[8], biv2[8], cr[8];
   if (bnred) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = n0 + c16 * 8 + j;
       bsc[j] = p.bn_coef[c]; bsh[j] = p.bn_coef[p.N + c]; bmu[j] = p.bn_coef[2 * p.N + c]; biv[j] = p.bn_coef[3 * p.N + c];
+      cr[j] = 0.f; bmu2[j] = dual ? p.bn_coef2[2 * p.N + c] : 0.f; biv2[j] = dual ? p.bn_coef2[3 * p.N + c] : 0.f;
     }
   }
   if (!fused) {
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     // out = (conv + addend * (addmask > 0)) * (outmask > 0) on the staged bf16 value, like igemm_kernel's epilogue (the identity-path
     // gradient and the ReLU masks of the data gradients, engine._block_bwd); two rows per step, every load ahead of the first store
     for (int R = rg; R < rows; R += 2 * G::RG) {
-      Vec16<bf16_t> av[2], mv[2], ov[2], yv[2];
+      Vec16<bf16_t> av[2], mv[2], ov[2], yv[2], y2v[2];
       bool live[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -449,6 +455,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
           if (p.addend && p.addmask) mv[i] = ldg16(p.addmask + off);
           if (p.outmask) ov[i] = ldg16(p.outmask + off);
           if (bnred) yv[i] = ldg16(p.bn_y + off);
+          if (dual) y2v[i] = ldg16(p.bn_y2 + off);
         }
       }
 #pragma unroll
@@ -475,8 +482,9 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
           for (int j = 0; j < 8; ++j) {
             const float yj = yv[i].get(j);
             float gj = v.get(j);
-            if (!(yj * bsc[j] + bsh[j] > 0.f)) gj = 0.f;
+            if (p.bn_selfmask && !(yj * bsc[j] + bsh[j] > 0.f)) gj = 0.f;
             cs[j] += gj; cq[j] += gj * (yj - bmu[j]) * biv[j];
+            if (dual) cr[j] += gj * (y2v[i].get(j) - bmu2[j]) * biv2[j];
           }
         } else if (p.stats) {
 #pragma unroll
@@ -487,15 +495,18 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   }
   if (p.stats || bnred) {
     __syncthreads();                                                // the staged tile has been read: its LDS is reused for the partial sums
-    float* part = reinterpret_cast<float*>(smem);                   // [RG row groups][2][BN]
+    float* part = reinterpret_cast<float*>(smem);                   // [RG row groups][3][BN]
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { part[(rg * 2 + 0) * G::BN + c16 * 8 + j] = cs[j]; part[(rg * 2 + 1) * G::BN + c16 * 8 + j] = cq[j]; }
+    for (int j = 0; j < 8; ++j) {
+      part[(rg * 3 + 0) * G::BN + c16 * 8 + j] = cs[j]; part[(rg * 3 + 1) * G::BN + c16 * 8 + j] = cq[j];
+      if (dual) part[(rg * 3 + 2) * G::BN + c16 * 8 + j] = cr[j];
+    }
     __syncthreads();
-    if (tid < 2 * G::BN) {
-      const int k = tid / G::BN, c = tid - k * G::BN;
+    for (int o = tid; o < (dual ? 3 : 2) * G::BN; o += 512) {
+      const int k = o / G::BN, c = o - k * G::BN;
       float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < G::RG; ++q) t += part[(q * 2 + k) * G::BN + c];
+      for (int q = 0; q < G::RG; ++q) t += part[(q * 3 + k) * G::BN + c];
       const int Rr = acc_replicas(p.N);
       if (bnred) acc_add_fixed(p.bn_facc, (size_t)Rr * 3 * p.N, ((size_t)(tm % Rr) * 3 + k) * p.N + n0 + c, t);
       else acc_add_fixed(p.stats, (size_t)Rr * 2 * p.N, (size_t)(tm % Rr) * 2 * p.N + (size_t)k * p.N + n0 + c, t);
@@ -529,18 +540,20 @@ int vqa_conv8p_ok(int B, int H, int W, int C, int N) {      // (H, W: the INPUT 
 // [B][H][W][Cout], w the packed [Cin][(tap, Cout)] operand of vqa_pack_transpose, taps mirrored).  stats: fixed-point BatchNorm
 // accumulator (vqa_bn_acc_words(2, N), caller-zeroed) receiving sum y | sum y^2 of the stored values, or NULL.
 // addend / addmask / outmask [B*H*W][N] bf16 or NULL: out = (conv + addend * (addmask > 0)) * (outmask > 0), the epilogue of vqa_igemm.
-// bn_y / bn_coef / bn_facc (all or none, not with stats): the BatchNorm-backward column sums of the stored tile (C8Params).
+// bn_y / bn_coef / bn_facc (all or none, not with stats): the BatchNorm-backward column sums of the stored tile (C8Params); bn_selfmask 1: the
+// ReLU behind that BatchNorm is recomputed from bn_y, 0: the tile is already masked; bn_y2 / bn_coef2: a second BatchNorm sharing the gradient.
 // stride: 1, or 2 (forward only: the 3x3 / 2 / pad 1 stage-entry convs; out is [B][(H+1)/2... ][N], i.e. Ho = (H - 1) / 2 + 1).
 // Tile: 224 x 256 (2 x 4 waves) when 256 divides N, else 448 x 128 (4 x 2 waves); 7/8 of the rows valid (196 / 392) when that divides
 // B*H*W -- the 14 x 14, 7 x 7 and 28 x 28 maps of the model: exactly 2, 1 and 4 rounds of 256 CUs at B = 512.
 int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stats, const void* addend, const void* addmask, const void* outmask,
-               const void* bn_y, const float* bn_coef, unsigned long long* bn_facc,
+               const void* bn_y, const float* bn_coef, unsigned long long* bn_facc, int bn_selfmask, const void* bn_y2, const float* bn_coef2,
                int B, int H, int W, int C, int N, int transposed, int stride, hipStream_t st) {
   if (!x || !w || !out || !vqa_conv8p_ok(B, H, W, C, N) || (stride != 1 && stride != 2) || (stride == 2 && transposed)) return VQA_EARG;
   C8Params p;
   if (addmask && !addend) return VQA_EARG;
   if ((bn_y != nullptr) != (bn_coef != nullptr) || (bn_y != nullptr) != (bn_facc != nullptr) || (bn_y && stats)) return VQA_EARG;
-  p.bn_y = (const bf16_t*)bn_y; p.bn_coef = bn_coef; p.bn_facc = bn_facc;
+  if ((bn_y2 != nullptr) != (bn_coef2 != nullptr) || (bn_y2 && !bn_y) || (bn_y2 && bn_selfmask)) return VQA_EARG;
+  p.bn_y = (const bf16_t*)bn_y; p.bn_coef = bn_coef; p.bn_facc = bn_facc; p.bn_selfmask = bn_selfmask; p.bn_y2 = (const bf16_t*)bn_y2; p.bn_coef2 = bn_coef2;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
   p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.outmask = (const bf16_t*)outmask;
   p.stride = stride; p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (W + 2 - 3) / stride + 1;

@@ -112,6 +112,8 @@ class HipEngine:
         self.conv8p_bwd_n_multiple = 128
         self.hoist_cross = True                   # cross-attention: layer 0's query projection beside the CNN, layers >= 1's K / V path (fwd + bwd) on the text stream
         self.use_c64p_epi = True                  # stage-1 conv1 data gradients (identity addend + masks) on the 8-wave patch kernel
+        self.fuse_hand_reduce = False             # ... and the previous block's bn2 (+ shortcut BN) backward sums in the epilogue of conv1's data gradient:
+                                                  # measured neutral (12.21-12.27 vs 12.21-12.23 ms/step: two more epilogue streams cost what the pass saves) -> off
         self.fuse_bn1_reduce = True               # bn1-backward column sums in the epilogue of conv2's data gradient (conv8p, stage 1: the patch kernel)
         self.use_conv8p_bwd = True                # ... also for the data gradients (they run beside the weight-gradient stream)
         self._accbuf = None
@@ -1136,7 +1138,7 @@ class HipEngine:
             self._off_path([dy2], lambda: K.wgrad3x3_c128(rec["a1"], dy2, LY.mat_of(G, self.E[p + ".conv2.weight"]), B, Ho, Wo))
         else:
             self._off_path([dy2], lambda: K.wgrad(dy2, rec["a1"], LY.mat_of(G, self.E[p + ".conv2.weight"]), M, Cout, 9 * Cout, g2, dtype=T))
-        slab1, nb1, facc1 = None, 0, None
+        slab1, nb1, facc1, handed_pre = None, 0, None, None
         if self._c64p_ok(B, Ho, Wo, Cout, Cout, 3, 1) and bacc and self.fuse_bn1_reduce:
             facc1 = self._acc(K.L.count("vqa_bn_acc_words", 3, Cout))      # (as below for conv8p: bn1's backward sums leave this launch)
             da1 = K.conv3x3_c64p_bnred(dy2, self._wflip(p + ".conv2.weight"), B, Ho, Wo, rec["y1"], rec["c1"], facc1)
@@ -1184,10 +1186,18 @@ class HipEngine:
             # stage 1: the patch kernel with the identity-path gradient and the ReLU masks in its per-tile epilogue (was the 128 x 64 igemm tile)
             dx = K.conv3x3_c64p_epi(dy1, self._wflip(p + ".conv1.weight"), B, H, W, addend=dout, addmask=out_act, outmask=outmask)
         elif self.use_conv8p_bwd and stride == 1 and self._c8p_ok(B, H, W, Cout, Cin, 3, stride, 1, bwd=True):
-            dx = K.conv8p(dy1, self.Wt(p + ".conv1.weight"), B, H, W, Cout, Cin, transposed=1, addend=dout, addmask=out_act, outmask=outmask)
+            bnred = None
+            if hand is not None and bacc and self.fuse_hand_reduce:
+                # dx is the gradient entering the previous block's bn2 (and its shortcut BatchNorm), already masked by that block's
+                # ReLU (outmask): their backward column sums leave this epilogue and that block skips its bn_bwd_reduce pass
+                hfacc = self._acc(K.L.count("vqa_bn_acc_words", 3, Cin))
+                bnred = (hand["y2"], hand["c2"], hfacc, False, hand.get("yd"), hand.get("cd"))
+                handed_pre = (hfacc, -1)
+            dx = K.conv8p(dy1, self.Wt(p + ".conv1.weight"), B, H, W, Cout, Cin, transposed=1, addend=dout, addmask=out_act, outmask=outmask,
+                          bnred=bnred)
         else:
             dx, _, _ = K.igemm(dy1, self.Wt(p + ".conv1.weight"), Md, Cin, 9 * Cout, geom_d1, dtype=T, transposed=1,
                                addend=dout, addmask=out_act, outmask=outmask)
         if self.capture is not None:
             self.capture[p] = dict(dout=dout, masked=masked, handed=hand is not None, dy2=dy2, dyd=dyd, da1=da1, dy1=dy1, dx=dx)
-        return dx, None
+        return dx, handed_pre

@@ -238,8 +238,11 @@ def conv8p(x, w, B, H, W, C, N, *, transposed=0, stride=1, stats_acc=None, out=N
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    bn_y, bn_coef, bn_facc = bnred if bnred is not None else (None, None, None)      # fused BatchNorm-backward column sums of the stored tile
+    # fused BatchNorm-backward column sums of the stored tile: (y, coef, facc) with the ReLU mask recomputed from y, or
+    # (y, coef, facc, False, y2 | None, coef2 | None) for an already masked tile (+ the shortcut BatchNorm sharing the gradient)
+    bn_y, bn_coef, bn_facc, bn_self, bn_y2, bn_coef2 = (tuple(bnred) + (True, None, None))[:6] if bnred is not None else (None, None, None, True, None, None)
     call("vqa_conv8p", ptr(x), ptr(w), ptr(out), ptr(stats_acc), ptr(addend), ptr(addmask), ptr(outmask), ptr(bn_y), ptr(bn_coef), ptr(bn_facc),
+         int(bool(bn_self)), ptr(bn_y2), ptr(bn_coef2),
          B, H, W, C, N, int(transposed), int(stride))
     if PROFILE is not None:
         e1.record()
