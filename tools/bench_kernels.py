@@ -56,7 +56,7 @@ for name, Cin, Cout, H, R, stride, pad in CONVS:
     print(f"{name:22s} wgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
 
 if not args.only or "c8p" in args.only:
-    for name, C, H in (("s3 256->256 14", 256, 14), ("s4 512->512 7", 512, 7)):
+    for name, C, H in (("s2 128->128 28", 128, 28), ("s3 256->256 14", 256, 14), ("s4 512->512 7", 512, 7)):
         x = torch.randn(B * H * H, C, device=dev).to(T)
         w = (torch.randn(C, 9 * C, device=dev) * 0.03).to(T)
         fl = 2.0 * B * H * H * C * 9 * C
@@ -65,6 +65,13 @@ if not args.only or "c8p" in args.only:
         print(f"{name:22s} conv8p fwd   {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
         t = timeit(lambda: K.conv8p(x, w, B, H, H, C, C, transposed=1), args.iters)
         print(f"{name:22s} conv8p dgrad {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
+        yb = torch.randn(B * H * H, C, device=dev).to(T)
+        cf = torch.stack([torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.3, torch.zeros(C, device=dev), torch.ones(C, device=dev)]).contiguous()
+        w3 = K.L.count("vqa_bn_acc_words", 3, C)
+        t = timeit(lambda: K.conv8p(x, w, B, H, H, C, C, transposed=1, bnred=(yb, cf, torch.zeros(w3, device=dev, dtype=torch.int64))), args.iters)
+        print(f"{name:22s} conv8p dgrad + bn1 backward sums {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
+        t = timeit(lambda: K.conv8p(x, w, B, H, H, C, C, transposed=1, addend=yb, outmask=yb), args.iters)
+        print(f"{name:22s} conv8p dgrad + addend + outmask  {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
 
 if not args.only or "c64" in args.only:
     H = 56
@@ -81,6 +88,14 @@ if not args.only or "c64" in args.only:
     print(f"c64 DMA patch conv fwd {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s   io {(2*x.numel())*2/t/1e12:5.2f} TB/s")
     t = timeit(lambda: K.conv3x3_c64p(dy, wfl, B, H, H), args.iters)
     print(f"c64 DMA patch dgrad    {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
+    cf = torch.stack([torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.3, torch.zeros(64, device=dev), torch.ones(64, device=dev)]).contiguous()
+    w3 = K.L.count("vqa_bn_acc_words", 3, 64)
+    t = timeit(lambda: K.conv3x3_c64p_bnred(dy, wfl, B, H, H, x, cf, torch.zeros(w3, device=dev, dtype=torch.int64)), args.iters)
+    print(f"c64 DMA patch dgrad + bn1 backward sums  {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: K.conv3x3_c64p_epi(dy, wfl, B, H, H, addend=x), args.iters)
+    print(f"c64 DMA patch dgrad + addend             {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: K.conv3x3_c64p_epi(dy, wfl, B, H, H, addend=x, outmask=x), args.iters)
+    print(f"c64 DMA patch dgrad + addend + outmask   {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
     t = timeit(lambda: K.wgrad3x3_c64(x, dy, dw, B, H, H), args.iters)
     print(f"c64 patch wgrad        {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF/s")
 
