@@ -249,6 +249,7 @@ def _run(args, real_stdout):
     trainer.step(*data)
     if rank == 0:
         K.PROFILE = []
+        K.PROFILE_VARIANTS = []
     trainer.step(*data)
     torch.cuda.synchronize()
     trainer.engine.two_streams = was
@@ -264,6 +265,11 @@ def _run(args, real_stdout):
                 continue
             a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
             a[0] += tsec; a[1] += flops; a[2] += 1; a[3] += nbytes
+        variants = {}                           # launches of one symbol that run different code paths (kernels.PROFILE_VARIANTS)
+        for sym, label, flops, e0, e1 in K.PROFILE_VARIANTS:
+            v = variants.setdefault(sym, {}).setdefault(label, [0.0, 0.0, 0])
+            v[0] += e0.elapsed_time(e1) * 1e-3; v[1] += flops; v[2] += 1
+        K.PROFILE_VARIANTS = []
         K.PROFILE = None
         gemm_time = sum(a[0] for a in agg.values())
         name, (tt, fl, n, nb) = max(agg.items(), key=lambda kv: kv[1][0])
@@ -297,6 +303,8 @@ def _run(args, real_stdout):
                 "algorithmic_bytes_per_launch": round(nb / n), "launches_per_step": n,
                 "avg_launch_us": round(tt / n * 1e6, 2), "flop_per_launch": fl / n,
                 "measured": "live HIP events on the launch stream, one single-stream step after the timed region",
+                "launch_groups": {lab: {"n": v[2], "avg_launch_us": round(v[0] / v[2] * 1e6, 2), "tflops": round(v[1] / v[0] / 1e12, 1)}
+                                  for lab, v in variants.get(name, {}).items()},
                 "kernel_time_ms_per_step": round(tt * 1e3, 3), "all_gemm_time_ms_per_step": round(gemm_time * 1e3, 3),
                 "flop_per_pair": flop_pair, "step_tflops": round(value / world * flop_pair / 1e12, 2),
                 "step_frac_of_mfma_peak": round(value / world * flop_pair / 1e12 / PEAK[args.dtype], 4),

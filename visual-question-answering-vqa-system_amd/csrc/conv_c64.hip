@@ -364,16 +364,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
       const int tap = kk >> 1, r = tap / 3, s_ = tap - r * 3;
       asm volatile("ds_read_b128 %0, %1" : "=v"(ring[kk]) : "v"(ec[s_][kk & 1] + (unsigned)r * rowstep));
     }
+    // epilogue inputs of a tile (EPI / BNRED): loaded one tile ahead -- for the block's first tile here, for tile t + 1 in the epilogue
+    // of tile t BEFORE that tile's output store, so that the (compiler-counted) wait for them never includes a store's acknowledgement
+    // (first version: loads at the top of their own tile, i.e. behind the previous tile's store: waves parked on vmcnt for 55-59 % of
+    // their life, MFMA pipe 28 % busy against 45 % for the plain variant; profiles/r04_sq_counters.json)
+    size_t ooff = (((size_t)b * p.H + oh0 + orow) * p.W + ow) * CH + wn * 32 + 8 * g;
+    Vec16<bf16_t> e_a, e_m, e_o;
+    auto epi_loads = [&](size_t off) __attribute__((always_inline)) {
+      if (EPI) {
+        e_a = ldg16(p.addend + off);
+        if (p.addmask) e_m = ldg16(p.addmask + off);
+        if (p.outmask) e_o = ldg16(p.outmask + off);
+      }
+      if (BNRED) e_a = ldg16(p.bn_y + off);
+    };
+    if (MODE && wm < mtiles) epi_loads(ooff);
     for (int mt = wm; mt < mtiles; mt += 4) {
       tile_addr(mt + 4 < mtiles ? mt + 4 : mt, en, orow_n, ow_n);   // the block's last tile re-reads itself (drained at the barrier)
-      const size_t ooff = (((size_t)b * p.H + oh0 + orow) * p.W + ow) * CH + wn * 32 + 8 * g;
-      Vec16<bf16_t> e_a, e_m, e_o;
-      if (EPI) {
-        e_a = ldg16(p.addend + ooff);
-        if (p.addmask) e_m = ldg16(p.addmask + ooff);
-        if (p.outmask) e_o = ldg16(p.outmask + ooff);
-      }
-      if (BNRED) e_a = ldg16(p.bn_y + ooff);
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int kk = 0; kk < 18; ++kk) {
@@ -420,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
         Vec16<bf16_t> v; v.raw = o;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+          if (h) __builtin_amdgcn_sched_barrier(0);                 // one half's 12 coefficient registers at a time (the kernel is at the 256-register limit)
           const f32x4 sc = *reinterpret_cast<const f32x4*>(cf + c0 + 4 * h), sh = *reinterpret_cast<const f32x4*>(cf + 64 + c0 + 4 * h),
                       mu = *reinterpret_cast<const f32x4*>(cf + 128 + c0 + 4 * h);
 #pragma unroll
@@ -432,7 +440,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64p_kernel(C64Params p) {
         }
       }
       (void)orow_c; (void)ow_c;
+      const size_t ooff_n = (((size_t)b * p.H + oh0 + orow) * p.W + ow) * CH + wn * 32 + 8 * g;      // (orow / ow are the next tile's by now)
+      if (MODE && mt + 4 < mtiles) epi_loads(ooff_n);
       *reinterpret_cast<u32x4*>(p.out + ooff) = o;
+      ooff = ooff_n;
     }
     // next patch landed.  vmcnt retires in issue order and this wave issued its DMA pieces BEFORE its output stores: with at
     // least 4 stores behind them, "at most 4 outstanding" already proves the pieces are in LDS -- the stores keep draining
@@ -1047,7 +1058,7 @@ int vqa_conv3x3_c64(const void* x, const void* w, void* out, float* stats, const
 // persistent grid of the 8-wave LDS-DMA patch kernel (= rows of its statistics slab), 0 when the shape is unsupported
 static int c64p_rows(int H, int W) {         // output rows per block of the 8-wave patch kernel for this shape, 0: unsupported
   for (int rbp = 8; rbp >= 4; rbp -= 4) {
-    const size_t shm = (size_t)2 * (rbp + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4;
+    const size_t shm = (size_t)2 * (rbp + 2) * (W + 2) * CH * 2 + 4 * 64 * 2 * 4 + 4 * 64 * 4;      // (what c64p_launch asks for)
     if (H % rbp == 0 && (rbp * W) % 16 == 0 && shm <= 160 * 1024) return rbp;
   }
   return 0;

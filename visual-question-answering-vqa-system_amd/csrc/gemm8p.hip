@@ -24,6 +24,7 @@
 // i.e. every buffer is restaged >= 2 phases after its last read (the guide's WAR rule incl. the one-barrier stagger) and read
 // one phase after the wait + barrier that retires its DMA (RAW rule); each wait is vmcnt(8): the wave's own 2 pieces of the four
 // youngest half-tiles stay in flight.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -399,6 +400,56 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #undef C8_RD
 #undef C8_WAIT
 
+  // ---- epilogue inputs (data gradients: identity-path gradient, ReLU masks, the BatchNorm input whose backward sums leave this launch).
+  // A thread owns column chunk c16 of rows rg, rg + RG, ... (<= 14 rows).  Its loads are issued NR rows at a time into two register
+  // sets: batch 0 BEFORE the tile is staged (in flight across the two barriers of epilogue 1), batch b + 1 before batch b is consumed,
+  // and always ahead of the stores of the batch before -- a wait for loads then never includes a store's acknowledgement.  (First
+  // version: 2 rows per step, loads of a step issued after the stores of the step before: 6-7 exposed round trips per tile, +17 us per
+  // tile and launch, i.e. +70-84 us on the four-tiles-per-CU stage-2 launches; profiles/r04_conv8p_epilogue.txt.)
+  const int c16 = tid % G::CPR, rg = tid / G::CPR;
+  const int rows = min(p.rpt, p.M - m0);
+  const bool bnred = p.bn_y != nullptr;
+  const bool fused = p.addend != nullptr || p.outmask != nullptr || p.bn_y != nullptr;
+  const bool dual = bnred && p.bn_y2 != nullptr;
+  constexpr int NRMAX = 4, TR = G::BMP / G::RG;                    // rows per thread (14)
+  struct EpiRow { Vec16<bf16_t> a, m, o, y, y2; };
+  EpiRow inA[NRMAX], inB[NRMAX];
+  // Straight-line code on purpose: stream presence is a template mask (bit 0 addend, 1 addmask, 2 outmask, 3 bn_y, 4 bn_y2), rows past
+  // the tile's last valid row re-read that row, and the batch loop is fully unrolled.  With a load under a branch, or a register set
+  // reloaded around a loop back-edge, hipcc guards each load with s_waitcnt vmcnt(0) (write-after-write on a register that MAY still
+  // be a pending load's destination): every load then waits for the one before it.
+  const bf16_t* const pa = p.addend ? p.addend : p.w;
+  const bf16_t* const pm = p.addmask ? p.addmask : p.w;
+  const bf16_t* const po = p.outmask ? p.outmask : p.w;
+  const bf16_t* const py = p.bn_y ? p.bn_y : p.w;
+  const bf16_t* const py2 = p.bn_y2 ? p.bn_y2 : p.w;
+  // (mask_c: std::integral_constant<int, MASK | NR << 8>: NR rows per batch -- 4 with one stream, 3 with two, 2 with all five: registers)
+  auto issue = [&](auto mask_c, int b, EpiRow (&e)[NRMAX]) __attribute__((always_inline)) {
+    constexpr int MASK = decltype(mask_c)::value & 255, NR = decltype(mask_c)::value >> 8;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      int R = rg + (b * NR + i) * G::RG;
+      R = R < rows ? R : rows - 1;
+      const size_t off = (size_t)(m0 + R) * p.N + n0 + c16 * 8;
+      // (the full set also serves launches WITHOUT some of the streams: those pointers are the weights, read at offset 0)
+      if (MASK & 1) e[i].a = ldg16(pa + (p.addend ? off : 0));
+      if (MASK & 2) e[i].m = ldg16(pm + (p.addmask ? off : 0));
+      if (MASK & 4) e[i].o = ldg16(po + (p.outmask ? off : 0));
+      if (MASK & 8) e[i].y = ldg16(py + (p.bn_y ? off : 0));
+      if (MASK & 16) e[i].y2 = ldg16(py2 + (p.bn_y2 ? off : 0));
+    }
+  };
+  // the three stream sets the engine uses get their own code; anything else takes the full set with absent streams pointed at the weights
+  const int smask = (p.addend ? 1 : 0) | (p.addmask ? 2 : 0) | (p.outmask ? 4 : 0) | (bnred ? 8 : 0) | (dual ? 16 : 0);
+  const int emode = !fused ? 0 : (smask == 8 ? 1 : (smask == 5 ? 2 : (smask == 1 ? 3 : 4)));
+  const bool ha = smask & 1, hm = smask & 2, ho = smask & 4;
+  using EM1 = std::integral_constant<int, 8 | 4 << 8>;  using EM2 = std::integral_constant<int, 5 | 3 << 8>;
+  using EM3 = std::integral_constant<int, 1 | 4 << 8>;  using EM4 = std::integral_constant<int, 31 | 2 << 8>;
+  if (emode == 1) issue(EM1{}, 0, inA);
+  else if (emode == 2) issue(EM2{}, 0, inA);
+  else if (emode == 3) issue(EM3{}, 0, inA);
+  else if (emode == 4) issue(EM4{}, 0, inA);
+
   // ---- epilogue 1: bf16 tile -> LDS  (acc[mi][nj][r] = out[row 112 wm + 16 mi + li][column 64 wn + 16 nj + 4 g + r])
   typedef __attribute__((ext_vector_type(2))) float f32x2_t;
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -412,18 +463,12 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
       o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[mi][nj][2], acc[mi][nj][3]}, bf16x2_t));
       *reinterpret_cast<u32x2_t*>(smem + (wm * 112 + mi * 16 + li) * G::LDC + (wn * 64 + nj * 16 + 4 * g) * 2) = o;
     }
-  __syncthreads();
   // ---- epilogue 2: full row segments out; column sums of the stored (bf16) values
-  const int c16 = tid % G::CPR, rg = tid / G::CPR;
   float cs[8], cq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { cs[j] = 0.f; cq[j] = 0.f; }
-  const int rows = min(p.rpt, p.M - m0);
-  const bool bnred = p.bn_y != nullptr;
-  const bool fused = p.addend != nullptr || p.outmask != nullptr || bnred;
-  const bool dual = bnred && p.bn_y2 != nullptr;
   float bsc[8], bsh[8], bmu[8], biv[8], bmu2[8], biv2[8], cr[8];
-  if (bnred) {
+  if (bnred) {                                                      // (the accumulators are dead: their registers take the coefficients, under the barrier)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = n0 + c16 * 8 + j;
@@ -431,6 +476,8 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
       cr[j] = 0.f; bmu2[j] = dual ? p.bn_coef2[2 * p.N + c] : 0.f; biv2[j] = dual ? p.bn_coef2[3 * p.N + c] : 0.f;
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the staged tile is visible after the barrier; NOT __syncthreads():
+  G8_BAR();                                                         // its vmcnt(0) would drain the loads issued above
   if (!fused) {
     for (int R = rg; R < rows; R += G::RG) {
       Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + R * G::LDC + c16 * 16);
@@ -442,56 +489,58 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     }
   } else {
     // out = (conv + addend * (addmask > 0)) * (outmask > 0) on the staged bf16 value, like igemm_kernel's epilogue (the identity-path
-    // gradient and the ReLU masks of the data gradients, engine._block_bwd); two rows per step, every load ahead of the first store
-    for (int R = rg; R < rows; R += 2 * G::RG) {
-      Vec16<bf16_t> av[2], mv[2], ov[2], yv[2], y2v[2];
-      bool live[2];
+    // gradient and the ReLU masks of the data gradients, engine._block_bwd)
+    auto consume = [&](auto mask_c, int b, EpiRow (&e)[NRMAX]) __attribute__((always_inline)) {
+      constexpr int NR = decltype(mask_c)::value >> 8;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        live[i] = R + G::RG * i < rows;
-        const size_t off = (size_t)(m0 + R + G::RG * i) * p.N + n0 + c16 * 8;
-        if (live[i]) {
-          if (p.addend) av[i] = ldg16(p.addend + off);
-          if (p.addend && p.addmask) mv[i] = ldg16(p.addmask + off);
-          if (p.outmask) ov[i] = ldg16(p.outmask + off);
-          if (bnred) yv[i] = ldg16(p.bn_y + off);
-          if (dual) y2v[i] = ldg16(p.bn_y2 + off);
-        }
-      }
+      for (int i = 0; i < NR; ++i) {
+        const int R = rg + (b * NR + i) * G::RG;
+        if (R >= rows) continue;
+        const size_t off = (size_t)(m0 + R) * p.N + n0 + c16 * 8;
+        Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + R * G::LDC + c16 * 16);
+        if (ha) {
+          if (hm) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (!live[i]) continue;
-        const size_t off = (size_t)(m0 + R + G::RG * i) * p.N + n0 + c16 * 8;
-        Vec16<bf16_t> v; v.raw = *reinterpret_cast<const u32x4*>(smem + (R + G::RG * i) * G::LDC + c16 * 16);
-        if (p.addend) {
-          if (p.addmask) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v.set(j, v.get(j) + (mv[i].get(j) > 0.f ? av[i].get(j) : 0.f));
+            for (int j = 0; j < 8; ++j) v.set(j, v.get(j) + (e[i].m.get(j) > 0.f ? e[i].a.get(j) : 0.f));
           } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v.set(j, v.get(j) + av[i].get(j));
+            for (int j = 0; j < 8; ++j) v.set(j, v.get(j) + e[i].a.get(j));
           }
         }
-        if (p.outmask) {
+        if (ho) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) if (!(ov[i].get(j) > 0.f)) v.set(j, 0.f);
+          for (int j = 0; j < 8; ++j) if (!(e[i].o.get(j) > 0.f)) v.set(j, 0.f);
         }
         stg16(p.out + off, v);
-        if (bnred) {                                                // (same arithmetic per element as bn_bwd_reduce_kernel<SELF>: the stored value, the recomputed ReLU mask)
+        if (bnred) {                                                // (same arithmetic per element as bn_bwd_reduce_kernel: the stored value, the recomputed ReLU mask)
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float yj = yv[i].get(j);
+            const float yj = e[i].y.get(j);
             float gj = v.get(j);
             if (p.bn_selfmask && !(yj * bsc[j] + bsh[j] > 0.f)) gj = 0.f;
             cs[j] += gj; cq[j] += gj * (yj - bmu[j]) * biv[j];
-            if (dual) cr[j] += gj * (y2v[i].get(j) - bmu2[j]) * biv2[j];
+            if (dual) cr[j] += gj * (e[i].y2.get(j) - bmu2[j]) * biv2[j];
           }
         } else if (p.stats) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { const float f = v.get(j); cs[j] += f; cq[j] += f * f; }
         }
       }
-    }
+    };
+    auto run = [&](auto mask_c) __attribute__((always_inline)) {
+      constexpr int NR = decltype(mask_c)::value >> 8, NB = (TR + NR - 1) / NR;
+#pragma unroll
+      for (int b = 0; b < NB; b += 2) {
+        if (b + 1 < NB) issue(mask_c, b + 1, inB);
+        consume(mask_c, b, inA);
+        if (b + 2 < NB) issue(mask_c, b + 2, inA);
+        if (b + 1 < NB) consume(mask_c, b + 1, inB);
+      }
+    };
+    if (emode == 1) run(EM1{});
+    else if (emode == 2) run(EM2{});
+    else if (emode == 3) run(EM3{});
+    else run(EM4{});
   }
   if (p.stats || bnred) {
     __syncthreads();                                                // the staged tile has been read: its LDS is reused for the partial sums

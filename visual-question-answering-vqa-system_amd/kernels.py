@@ -19,6 +19,7 @@ LOADER_NHWC, LOADER_STEM = 0, 1
 # Optional live profiling (bench.py): when PROFILE is a list, igemm/wgrad bracket their launch with events on the
 # launch stream and append (kernel symbol, algorithmic FLOPs, start event, end event, algorithmic bytes).
 PROFILE = None
+PROFILE_VARIANTS = []        # (symbol, variant label, FLOPs, start event, end event) of launches whose symbol covers several code paths
 
 # HBM-bound entries (no FLOPs worth counting): algorithmic bytes of one call from its C-ABI argument list -- the tensors the op
 # must read and write once; recorded as ("hbm:<class>:<entry>", 0, e0, e1, bytes) while PROFILE is a list.
@@ -147,6 +148,12 @@ def c64p_blocks(B, H, W) -> int:
     return L.count("vqa_conv3x3_c64p_blocks", B, H, W)
 
 
+def _c64p_sym(H, W, mode):
+    """The symbol rocprofv3 prints for a vqa_conv3x3_c64p* launch: <output rows per block (conv_c64.hip c64p_rows), MODE 0 plain | 1 EPI | 2 BNRED>."""
+    rbp = 8 if (H % 8 == 0 and 2 * 10 * (W + 2) * 128 + 3072 <= 160 * 1024) else 4
+    return "conv3x3_c64p_kernel<%d, %d>" % (rbp, mode)
+
+
 def conv3x3_c64p(x, w, B, H, W, *, want_stats=False, stats_acc=None):
     """bf16 3x3/1 conv, 64->64 channels, 8-wave LDS-DMA patch kernel (no epilogue inputs).  Returns (out, stats slab | None, blocks).
     stats_acc: a zeroed int64 [2*64 + 1] fixed-point accumulator that receives the BatchNorm sums instead of a slab."""
@@ -159,7 +166,7 @@ def conv3x3_c64p(x, w, B, H, W, *, want_stats=False, stats_acc=None):
     call("vqa_conv3x3_c64p", ptr(x), ptr(w), ptr(out), ptr(stats), B, H, W, int(stats_acc is not None))
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("conv3x3_c64p_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
+        PROFILE.append((_c64p_sym(H, W, 0), 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
     return out, stats, nb
 
 
@@ -173,7 +180,7 @@ def conv3x3_c64p_bnred(x, w, B, H, W, bn_y, bn_coef, bn_facc):
     call("vqa_conv3x3_c64p_bnred", ptr(x), ptr(w), ptr(out), ptr(bn_y), ptr(bn_coef), ptr(bn_facc), B, H, W)
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("conv3x3_c64p_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 3 * B * H * W * 64 * 2))
+        PROFILE.append((_c64p_sym(H, W, 2), 2.0 * B * H * W * 64 * 576, e0, e1, 3 * B * H * W * 64 * 2))
     return out
 
 
@@ -187,7 +194,7 @@ def conv3x3_c64p_epi(x, w, B, H, W, *, addend, addmask=None, outmask=None):
     call("vqa_conv3x3_c64p_epi", ptr(x), ptr(w), ptr(out), ptr(addend), ptr(addmask), ptr(outmask), B, H, W)
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("conv3x3_c64p_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, (3 + (addmask is not None) + (outmask is not None)) * B * H * W * 64 * 2))
+        PROFILE.append((_c64p_sym(H, W, 1), 2.0 * B * H * W * 64 * 576, e0, e1, (3 + (addmask is not None) + (outmask is not None)) * B * H * W * 64 * 2))
     return out
 
 
@@ -206,7 +213,7 @@ def conv3x3_c64p_bn(y, acc, bn, w, B, H, W, count, *, want_stats=False, stats_ac
          int(stats_acc is not None), float(count), momentum, eps)
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("conv3x3_c64p_kernel", 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
+        PROFILE.append((_c64p_sym(H, W, 0), 2.0 * B * H * W * 64 * 576, e0, e1, 2 * B * H * W * 64 * 2))
     return out, stats, nb, coef
 
 
@@ -246,7 +253,12 @@ def conv8p(x, w, B, H, W, C, N, *, transposed=0, stride=1, stats_acc=None, out=N
          B, H, W, C, N, int(transposed), int(stride))
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("conv8p_kernel<2, 4>" if N % 256 == 0 else "conv8p_kernel<4, 2>",      # the symbol rocprofv3 prints (the C dispatch: 256 | N)
+        sym = "conv8p_kernel<2, 4>" if N % 256 == 0 else "conv8p_kernel<4, 2>"      # the symbol rocprofv3 prints (the C dispatch: 256 | N)
+        # (the same symbol runs with and without epilogue inputs -- identity-path gradient / masks / the fused BatchNorm-backward sums:
+        #  PROFILE_VARIANTS lets bench.py show the two groups of launches apart)
+        PROFILE_VARIANTS.append((sym, "with epilogue inputs" if (addend is not None or outmask is not None or bnred is not None) else "plain",
+                                 2.0 * out.shape[0] * N * 9 * C, e0, e1))
+        PROFILE.append((sym,
                         2.0 * out.shape[0] * N * 9 * C, e0, e1, (B * H * W * C + out.shape[0] * N + N * 9 * C) * 2))
     return out
 
