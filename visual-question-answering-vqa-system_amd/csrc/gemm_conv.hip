@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
   constexpr int WN = BN / 64, WM = NW / WN, TM = BM / WM, MT = TM / 16, NT = 4;
   constexpr int AV = BM / RPP, BV = BN / RPP;
   constexpr int SMEM = IGemmCfg<T, BM, BN, BK, ST, WIN>::SMEM;
-  static_assert(ST == 2 || (ST == 3 && LOADER != LOADER_STEM), "ring depth");
+  static_assert(ST == 2 || ((ST == 3 || ST == 4) && LOADER != LOADER_STEM), "ring depth");
   static_assert(!WIN || (LOADER == LOADER_NHWC && ST == 2 && sizeof(T) == 2 && CPR == 8), "window loader: bf16 NHWC, double buffered");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* As = reinterpret_cast<T*>(smem);
@@ -443,22 +443,30 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
 
   // p.dbg (VQA_IGEMM_DBG, measurement only): bit 0 = no DMA inside the K loop, bit 1 = no MFMA / LDS-read phase
   const bool dbg_nodma = p.dbg & 1, dbg_nomma = p.dbg & 2;
-  if constexpr (ST == 3) {
-    // 3-slot ring, two K steps of DMA in flight: the barrier that ends step kt only waits for tile kt+1 (counted vmcnt: the
-    // AV + BV LDS-DMA instructions of tile kt+2 may still be outstanding), so a tile has two compute phases to land.
-    if (nk > 0) gload(0);
-    if (nk > 1) {
-      gload(1);
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(AV + BV) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (ST >= 3) {
+    // ST-slot ring, ST - 1 K steps of DMA in flight: the barrier that ends step kt only waits for tile kt + 1 (counted vmcnt: the
+    // AV + BV LDS-DMA instructions of each later tile may still be outstanding), so a tile has ST - 1 compute phases to land.
+    // (Round 4 tried it, 3 and 4 slots, on the dense Linears of the token side -- K = 256 ... 1024, 4 ... 16 K steps of ~0.1 us of MFMA
+    // work each: 15-50 % SLOWER wherever the launch is not at the ~11 us floor anyway (fewer workgroups per CU); tools/token_gemm_sweep.py.)
+#pragma unroll
+    for (int t = 0; t < ST - 1; ++t)
+      if (t < nk) gload(t);
+    auto wait_tiles = [&](int outstanding) __attribute__((always_inline)) {     // wait until at most `outstanding` tiles are in flight, then barrier
+      if (outstanding >= 2 && ST >= 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (AV + BV)) : "memory");
+      else if (outstanding == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(AV + BV) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    {
+      const int issued = nk < ST - 1 ? nk : ST - 1;
+      wait_tiles(issued - 1);                                       // tile 0 has landed
     }
     for (int kt = 0; kt < nk; ++kt) {
-      const bool more = (kt + 2 < nk) && !dbg_nodma;
-      if (more) gload(kt + 2);           // slot (kt+2)%3 == (kt-1)%3: every wave finished reading it before the last barrier
-      if (!dbg_nomma) compute(kt % 3);
-      if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(AV + BV) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const bool more = (kt + ST - 1 < nk) && !dbg_nodma;
+      if (more) gload(kt + ST - 1);        // slot (kt - 1) % ST: every wave finished reading it before the last barrier
+      if (!dbg_nomma) compute(kt % ST);
+      const int issued = dbg_nodma ? (nk < ST - 1 ? nk : ST - 1) : (kt + ST < nk ? kt + ST : nk);      // tiles issued so far
+      const int left = issued - (kt + 2);                            // tiles that may stay in flight once tile kt + 1 has landed
+      wait_tiles(left < 0 ? 0 : left);
     }
   } else {
     if (nk > 0) { gload(0); if (!DMA) sstore(0); }
@@ -1347,6 +1355,8 @@ static void igemm_tile(int M, int N, int* bm, int* bn) {
   *bm = 128; *bn = N <= 64 ? 64 : 128;
   long tiles = (long)((M + *bm - 1) / *bm) * ((N + *bn - 1) / *bn);
   if (tiles < 384) { *bm = 64; *bn = 64; }
+  const int force = vqa_env_int("VQA_IGEMM_TILE", 0);      // measurement only (tools/token_gemm_sweep.py): BM * 1000 + BN
+  if (force == 128128 || force == 128064 || force == 64064) { *bm = force / 1000; *bn = force % 1000; }
 }
 
 // The ONE place that picks the template instantiation of a launch; vqa_igemm_variant() reports it to the host (parity tests assert
@@ -1377,6 +1387,26 @@ static int igemm_dispatch(const IGemmParams& p, int loader, hipStream_t st) {
       default: break;
     }
   }
+#ifdef VQA_ABLATION     // measurement builds only (tools/token_gemm_sweep.py; profiles/r04_token_gemm_sweep.txt: deeper rings are SLOWER)
+  if constexpr (sizeof(T) == 2) {
+    // dense Linear launches (1x1 "conv", stride 1): a deeper DMA ring -- these are 4-16 K steps of almost no MFMA work each
+    const int ring = vqa_env_int("VQA_IGEMM_ST", 2);
+    if (ring >= 3 && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0) {
+      if (ring == 3) switch (v) {
+        case 128 * 10000 + 128 * 10: return launch_igemm<T, 128, 128, LOADER_NHWC, 4, 64, 2, 3>(p, st);
+        case 128 * 10000 + 64 * 10: return launch_igemm<T, 128, 64, LOADER_NHWC, 4, 64, 2, 3>(p, st);
+        case 64 * 10000 + 64 * 10: return launch_igemm<T, 64, 64, LOADER_NHWC, 4, 64, 2, 3>(p, st);
+        default: break;
+      }
+      else switch (v) {
+        case 128 * 10000 + 128 * 10: return launch_igemm<T, 128, 128, LOADER_NHWC, 4, 64, 2, 4>(p, st);
+        case 128 * 10000 + 64 * 10: return launch_igemm<T, 128, 64, LOADER_NHWC, 4, 64, 2, 4>(p, st);
+        case 64 * 10000 + 64 * 10: return launch_igemm<T, 64, 64, LOADER_NHWC, 4, 64, 2, 4>(p, st);
+        default: break;
+      }
+    }
+  }
+#endif
   switch (v) {
     case 128 * 10000 + 128 * 10: return launch_igemm<T, 128, 128, LOADER_NHWC>(p, st);
     case 128 * 10000 + 64 * 10: return launch_igemm<T, 128, 64, LOADER_NHWC>(p, st);
