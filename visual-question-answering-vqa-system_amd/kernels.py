@@ -259,7 +259,8 @@ def conv8p(x, w, B, H, W, C, N, *, transposed=0, stride=1, stats_acc=None, out=N
         PROFILE_VARIANTS.append((sym, "with epilogue inputs" if (addend is not None or outmask is not None or bnred is not None) else "plain",
                                  2.0 * out.shape[0] * N * 9 * C, e0, e1))
         PROFILE.append((sym,
-                        2.0 * out.shape[0] * N * 9 * C, e0, e1, (B * H * W * C + out.shape[0] * N + N * 9 * C) * 2))
+                        2.0 * out.shape[0] * N * 9 * C, e0, e1,
+                        (B * H * W * C + out.shape[0] * N * (1 + sum(t is not None for t in (addend, addmask, outmask, bn_y, bn_y2))) + N * 9 * C) * 2))
     return out
 
 
