@@ -219,6 +219,7 @@ struct C8Params {
   // BatchNorm sharing g -> the third row, sum g * xhat(bn_y2) (what bn_bwd_reduce_kernel<false, DUAL> leaves)
   int bn_selfmask; const bf16_t* bn_y2; const float* bn_coef2;
   int M, N, K, B, H, W, C, transposed, rpt, tiles_n, ntiles, cpk_shift;
+  int dbg;   // VQA_C8P_DBG, -DVQA_ABLATION builds only (WRONG results, timing diagnostics): 1 every A piece of a half-tile re-fetches the first one's source, 2 the same for B, 4 no MFMAs
   int Ho, Wo, stride;                 // output map (= H, W for stride 1); forward convs also run with stride 2 (the stage-entry 3x3 / 2 convs)
   unsigned x_bytes, w_bytes;
 };
@@ -303,14 +304,22 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
       }
 #pragma unroll
       for (int h = 0; h < nk; ++h)
+#ifdef VQA_ABLATION
+        dma16_g8(rsX, base + (unsigned)((w * nk + h) * 1024), okt ? voffA[(p.dbg & 1) ? k0 : k0 + h] : OOB_G8, okt ? cc * 128 : 0);
+#else
         dma16_g8(rsX, base + (unsigned)((w * nk + h) * 1024), okt ? voffA[k0 + h] : OOB_G8, okt ? cc * 128 : 0);   // (scalar offset: wave-uniform)
+#endif
     } else {
 #pragma unroll
       for (int h = 0; h < G::N_B; ++h) {
         const int pc = w * G::N_B + h, r0 = pc * 8;                  // buffer rows: 32 of the 64 columns of each N group
         const bool okp = okt && r0 < G::B_ROWS;
         const int col = (r0 / 32) * 64 + (r0 % 32) + (which == 3 ? 32 : 0);
+#ifdef VQA_ABLATION
+        dma16_g8(rsW, base + (unsigned)(pc * 1024), okp ? ((pc & 1) ? voffB1 : voffB0) : OOB_G8, okp ? ((n0 + ((p.dbg & 2) ? 0 : col)) * p.K + t * G8_BK) * 2 : 0);
+#else
         dma16_g8(rsW, base + (unsigned)(pc * 1024), okp ? ((pc & 1) ? voffB1 : voffB0) : OOB_G8, okp ? ((n0 + col) * p.K + t * G8_BK) * 2 : 0);
+#endif
       }
     }
   };
@@ -331,6 +340,11 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 
 #define C8_RD(dst, off) dst = *reinterpret_cast<const bf16x8*>(smem + d * G::BUF + (off))
 #define C8_WAIT() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::INFLIGHT) : "memory")
+#ifdef VQA_ABLATION
+#define C8_COMPUTE(AF, BFR, MI, NJ, NI) if (!(p.dbg & 4)) { G8_COMPUTE(AF, BFR, MI, NJ, NI); }
+#else
+#define C8_COMPUTE(AF, BFR, MI, NJ, NI) G8_COMPUTE(AF, BFR, MI, NJ, NI)
+#endif
 
   stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(2, 1);
   C8_WAIT();                                                        // A first (0), B first (0) landed (this wave's pieces)
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     C8_WAIT();                                                      // B second (t) landed -> read in P2
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    G8_COMPUTE(a0, b0, 0, 0, 4);
+    C8_COMPUTE(a0, b0, 0, 0, 4);
     G8_BAR();
     // ---------------- P2: rows 0-63 x columns 32-63
 #pragma unroll
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     C8_WAIT();                                                      // A second (t) landed -> read in P3
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    G8_COMPUTE(a0, b1, 0, 2, 4);
+    C8_COMPUTE(a0, b1, 0, 2, 4);
     G8_BAR();
     // ---------------- P3: rows 64-111 x columns 32-63
 #pragma unroll
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     C8_WAIT();                                                      // A first (t + 1) landed -> read in P4
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    G8_COMPUTE(a1, b1, 4, 2, 3);
+    C8_COMPUTE(a1, b1, 4, 2, 3);
     G8_BAR();
     // ---------------- P4: rows 64-111 x columns 0-31; the A-first fragments of the NEXT K tile
 #pragma unroll
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     C8_WAIT();                                                      // B first (t + 1) landed -> read in P1 of the next K tile
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    G8_COMPUTE(a1, b0, 4, 0, 3);
+    C8_COMPUTE(a1, b0, 4, 0, 3);
     G8_BAR();
   }
 #undef C8_RD_AT
@@ -606,7 +620,7 @@ int vqa_conv8p(const void* x, const void* w, void* out, unsigned long long* stat
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.out = (bf16_t*)out; p.stats = stats;
   p.addend = (const bf16_t*)addend; p.addmask = (const bf16_t*)addmask; p.outmask = (const bf16_t*)outmask;
   p.stride = stride; p.Ho = (H + 2 - 3) / stride + 1; p.Wo = (W + 2 - 3) / stride + 1;
-  p.M = B * p.Ho * p.Wo; p.N = N; p.K = 9 * C; p.B = B; p.H = H; p.W = W; p.C = C; p.transposed = transposed;
+  p.M = B * p.Ho * p.Wo; p.N = N; p.K = 9 * C; p.B = B; p.H = H; p.W = W; p.C = C; p.transposed = transposed; p.dbg = vqa_env_int("VQA_C8P_DBG", 0);
   p.x_bytes = (unsigned)((size_t)B * H * W * C * 2); p.w_bytes = (unsigned)((size_t)N * 9 * C * 2);
   const bool wide = N % 256 == 0;
   const int bmp = wide ? 224 : 448;
