@@ -75,6 +75,8 @@ int vqa_conv3x3_c64p(const void* x, const void* w, void* out, float* stats, int 
 /* Round 4 -- the 256 x 256 x 64 8-phase GEMM core (csrc/gemm8p.hip): C[M][N] = A[M][K] . B[N][K]^T, bf16 operands, fp32 accumulation,
  * bf16 result; M % 256 == 0, N % 256 == 0, K % 64 == 0.  The dense form of the tile that vqa_conv8p runs as an implicit GEMM. */
 int vqa_gemm8p(const void* A, const void* B, void* C, int M, int N, int K, hipStream_t stream);
+/* the same product on the four-wave kernel (one wave per SIMD, 128 x 128 wave tiles in the accumulator registers; same shape rules) */
+int vqa_gemm4w(const void* A, const void* B, void* C, int M, int N, int K, hipStream_t stream);
 /* vqa_conv8p: the same tile as an implicit-GEMM 3x3 / stride 1 / pad 1 convolution over NHWC bf16 (models/cnn_backbone.py:182-187 at
  * 256 / 512 channels): out[B*H*W][N] = conv(x [B][H][W][C], w [N][(r, s, c)]) with transposed = 0; with transposed = 1 the stride-1 data
  * gradient (x = dy [B][H][W][Cout], w = the [Cin][(tap, Cout)] pack of vqa_pack_transpose, taps mirrored).  Tiles hold 196 valid output

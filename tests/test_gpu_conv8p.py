@@ -12,20 +12,25 @@ DEV = "cuda"
 bf = torch.bfloat16
 
 
+@pytest.mark.parametrize("entry", ["vqa_gemm8p", "vqa_gemm4w"])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 256, 128), (256, 512, 192), (1024, 768, 2304), (768, 256, 4608)])
-def test_gemm8p_matches_matmul(M, N, K):
+def test_gemm8p_matches_matmul(M, N, K, entry):
     L = sub("_lib")
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(DEV, bf)
     B = torch.randn(N, K, generator=g).to(DEV, bf)
     C = torch.full((M, N), float("nan"), device=DEV, dtype=bf)
-    L.call("vqa_gemm8p", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K)
+    L.call(entry, A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K)
     torch.cuda.synchronize()
     ref = A.float() @ B.float().t()
     assert torch.isfinite(C.float()).all()
     assert (C.float() - ref).abs().max().item() <= 6e-3 * ref.abs().max().item()
     with pytest.raises(RuntimeError):
-        L.call("vqa_gemm8p", A.data_ptr(), B.data_ptr(), C.data_ptr(), M + 1, N, K)
+        L.call(entry, A.data_ptr(), B.data_ptr(), C.data_ptr(), M + 1, N, K)
+    if entry == "vqa_gemm4w":                                        # same K order per output element as the 8-phase kernel: same bits
+        C2 = torch.empty_like(C)
+        L.call("vqa_gemm8p", A.data_ptr(), B.data_ptr(), C2.data_ptr(), M, N, K)
+        assert torch.equal(C, C2)
 
 
 @pytest.mark.parametrize("B,H,W,C,N", [(4, 28, 28, 128, 256), (8, 14, 14, 256, 512), (3, 9, 11, 64, 256)])

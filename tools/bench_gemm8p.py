@@ -31,9 +31,10 @@ for M, N, Kd in [(4096, 4096, 4096), (8192, 8192, 8192), (100352, 256, 2304), (6
     err = (C[rows].float() - ref).abs().max().item() / ref.abs().max().item()
     fl = 2.0 * M * N * Kd
     t8 = timeit(lambda: L.call("vqa_gemm8p", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, Kd))
+    t4 = timeit(lambda: L.call("vqa_gemm4w", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, Kd))
     tt = timeit(lambda: torch.matmul(A, B.t()))
     ti = timeit(lambda: K.igemm(A, B, M, N, Kd, K.linear_geom(M, Kd), dtype=bf, out=C))
-    print(f"M={M:6d} N={N:5d} K={Kd:5d}: gemm8p {t8*1e6:8.1f} us {fl/t8/1e12:7.1f} TF/s | torch.matmul {tt*1e6:8.1f} us {fl/tt/1e12:7.1f} | igemm 128x128 {ti*1e6:8.1f} us {fl/ti/1e12:7.1f} | rel err {err:.2e}", flush=True)
+    print(f"M={M:6d} N={N:5d} K={Kd:5d}: gemm8p {t8*1e6:8.1f} us {fl/t8/1e12:7.1f} TF/s | gemm4w {t4*1e6:8.1f} us {fl/t4/1e12:7.1f} TF/s | torch.matmul {tt*1e6:8.1f} us {fl/tt/1e12:7.1f} | igemm 128x128 {ti*1e6:8.1f} us {fl/ti/1e12:7.1f} | rel err {err:.2e}", flush=True)
 
 print("--- 3x3 convs at B=512 (forward with BN statistics; data gradient plain): conv8p vs the 128x128 window-loader igemm")
 for name, C, H in [("stage2 128->128 28x28", 128, 28), ("stage3 256->256 14x14", 256, 14), ("stage4 512->512 7x7", 512, 7)]:

@@ -18,6 +18,7 @@ P, I, F, D, LL, ULL = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong, 
 # name -> argument ctypes (all return int; last argument is always the stream unless noted)
 SIGNATURES = {
     "vqa_gemm8p": [P, P, P, I, I, I, P],
+    "vqa_gemm4w": [P, P, P, I, I, I, P],
     "vqa_conv8p_ok": [I, I, I, I, I],
     "vqa_conv8p": [P, P, P, P, P, P, P, P, P, P, I, P, P, I, I, I, I, I, I, I, P],
     "vqa_igemm_mtiles": [I, I, I],

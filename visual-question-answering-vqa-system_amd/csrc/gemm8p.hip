@@ -194,6 +194,121 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// gemm4w_kernel (round 4, the OTHER structure: tools/bench_gemm8p.py): the same 256 x 256 x 64 tile on FOUR waves, one per SIMD, each a
+// 128 x 128 wave tile = 64 accumulator tiles (256 registers in the accumulator half of the 512-register file).  profiles/r04_conv8p_diag.txt:
+// at two waves per SIMD the 8-phase loop is bound by its own phase structure (a fragment-read + wait + barrier chain in front of every
+// 16-MFMA segment); here a K tile is ONE barrier and 128 MFMAs per wave:
+//   fragments are double-buffered per 32-deep K step (16 ds_read_b128 per step, issued one step ahead, counted lgkmcnt);
+//   the barrier sits in the MIDDLE of the second K step's MFMAs: by then every wave has read all of K tile t, so K tile t + 2 is staged
+//   into that buffer right behind it (1.5 K tiles = ~3000 cycles of lead for the LDS-DMA) and the first fragments of K tile t + 1 are read
+//   under the remaining 32 MFMAs;
+//   LDS: two buffers of A [256][128 B] | B [256][128 B] (128 KB), 16-byte slot XORed with (row >> 1) & 7 on the DMA source side.
+//   The MFMAs are inline asm with "+a" accumulators: left to itself hipcc spread the 64 accumulator tiles over both halves of the file
+//   and moved 188 registers each way between them per K tile.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NP3>
+__global__ __launch_bounds__(256, 1) void gemm4w_kernel(G8Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  int tile;
+  {
+    const int nwg = (int)gridDim.x, orig = (int)blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * G8_BM, n0 = tn * G8_BN;
+  const unsigned long long aa = (unsigned long long)p.A, ba = (unsigned long long)p.B;
+  const i32x4_g8 rsA = {(int)(unsigned)aa, (int)((unsigned)(aa >> 32) & 0xffffu), (int)p.a_bytes, 0x00020000};
+  const i32x4_g8 rsB = {(int)(unsigned)ba, (int)((unsigned)(ba >> 32) & 0xffffu), (int)p.b_bytes, 0x00020000};
+  const int dr = lane >> 3, dc = lane & 7;
+  const int voff0 = dr * p.K * 2 + ((dc ^ (dr >> 1)) << 4), voff1 = dr * p.K * 2 + ((dc ^ (dr >> 1) ^ 4) << 4);   // even / odd piece (row bit 3)
+  const int nkt = p.K / G8_BK;
+  auto piece = [&](int t, int n) __attribute__((always_inline)) {     // piece n (0..15) of this wave for K tile t -> buffer t & 1 (32 A + 32 B pieces of 8 rows)
+    const unsigned base = lds0 + (unsigned)((t & 1) * 65536);
+    const bool ok = t < nkt;
+    const int pc = w + 4 * n, isB = pc >= 32, q = isB ? pc - 32 : pc;
+    const int so = ((isB ? n0 : m0) + q * 8) * p.K * 2 + t * (G8_BK * 2);
+    dma16_g8(isB ? rsB : rsA, base + (unsigned)((isB ? 32768 : 0) + q * 1024), ok ? ((q & 1) ? voff1 : voff0) : OOB_G8, ok ? so : 0);
+  };
+  const int fl = (li >> 1) & 7;
+  const unsigned sk[2] = {(unsigned)((g ^ fl) << 4), (unsigned)((g ^ fl ^ 4) << 4)};
+  const unsigned ra = (unsigned)((wr * 128 + li) * 128), rb = (unsigned)(32768 + (wc * 128 + li) * 128);
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[2][8], bf[2][8];
+  // one row of 8 MFMAs (accumulator row i, K step kk), then -- between the rows -- a share of the next fragments / the next DMA pieces
+#define G4_ROW(kk, i) _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                  \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bf[kk][j]), "v"(af[kk][i]))
+#define G4_RDA(kk, buf, i) af[kk][i] = *reinterpret_cast<const bf16x8*>(smem + (buf) * 65536 + ra + (i) * 2048 + sk[kk])
+#define G4_RDB(kk, buf, i) bf[kk][i] = *reinterpret_cast<const bf16x8*>(smem + (buf) * 65536 + rb + (i) * 2048 + sk[kk])
+  // NP3: pieces of K tile t + 1 issued behind the barrier of tile t - 1 (segment 3); the rest in the next segment 1
+#pragma unroll
+  for (int n = 0; n < 16; ++n) piece(0, n);
+#pragma unroll
+  for (int n = 0; n < NP3; ++n) piece(1, n);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP3) : "memory");         // K tile 0 landed (this wave's pieces)
+  G8_BAR();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { G4_RDA(0, 0, i); G4_RDB(0, 0, i); }
+  for (int t = 0; t < nkt; ++t) {
+    const int d = t & 1;
+    // seg 1: K step 0 (64 MFMAs) + the fragments of K step 1 + the remaining pieces of K tile t + 1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (i < 4) { G4_RDA(1, d, 2 * i); G4_RDB(1, d, 2 * i); G4_RDA(1, d, 2 * i + 1); G4_RDB(1, d, 2 * i + 1); }
+      if (NP3 + 2 * i < 16) piece(t + 1, NP3 + 2 * i);
+      if (NP3 + 2 * i + 1 < 16) piece(t + 1, NP3 + 2 * i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      G4_ROW(0, i);
+    }
+    // seg 2: first half of K step 1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_barrier(0); G4_ROW(1, i); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // K tile t + 1 landed; every wave is past its last read of K tile t
+    G8_BAR();
+    // seg 3: second half of K step 1 + the first fragments of K tile t + 1 + the first pieces of K tile t + 2 (into the buffer just freed)
+#pragma unroll
+    for (int i = 4; i < 8; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      G4_RDA(0, d ^ 1, 2 * (i - 4)); G4_RDB(0, d ^ 1, 2 * (i - 4)); G4_RDA(0, d ^ 1, 2 * (i - 4) + 1); G4_RDB(0, d ^ 1, 2 * (i - 4) + 1);
+#pragma unroll
+      for (int n = (i - 4) * NP3 / 4; n < (i - 3) * NP3 / 4; ++n) piece(t + 2, n);
+      __builtin_amdgcn_sched_barrier(0);
+      G4_ROW(1, i);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the out-of-range tail pieces, the dangling fragment reads
+#undef G4_ROW
+#undef G4_RDA
+#undef G4_RDB
+  // ---- epilogue: acc[mi][nj][r] = C[m0 + 128 wr + 16 mi + li][n0 + 128 wc + 16 nj + 4 g + r]
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const size_t row = (size_t)(m0 + wr * 128 + mi * 16 + li);
+#pragma unroll
+    for (int nj = 0; nj < 8; ++nj) {
+      const int col = n0 + wc * 128 + nj * 16 + 4 * g;
+      u32x2_t o;
+      o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[mi][nj][0], acc[mi][nj][1]}, bf16x2_t));
+      o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[mi][nj][2], acc[mi][nj][3]}, bf16x2_t));
+      *reinterpret_cast<u32x2_t*>(p.C + row * p.N + col) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // The same schedule as an implicit-GEMM 3x3 / stride 1 / pad 1 convolution (forward, or the data gradient with the packed
 // [Cin][(tap, Cout)] operand and mirrored taps), NHWC bf16, for the 14 x 14 and 7 x 7 stages of the model (256 and 512 channels).
 // TILE SHAPE = QUANTISATION: at B = 512 those layers have M = 100 352 / 25 088 output pixels; 256-row tiles give 392 / 196 tiles for
@@ -579,6 +694,34 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 
 extern "C" {
 // C[M][N] = A[M][K] . B[N][K]^T, bf16 in / fp32 accumulate / bf16 out.  M % 256 == 0, N % 256 == 0, K % 64 == 0.
+// the same product on the four-wave / one-wave-per-SIMD kernel (gemm4w_kernel)
+int vqa_gemm4w(const void* A, const void* B, void* C, int M, int N, int K, hipStream_t st) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || M % G8_BM || N % G8_BN || K % G8_BK) return VQA_EARG;
+  const size_t ab = (size_t)M * K * 2, bb = (size_t)N * K * 2;
+  if (ab >= 0x7fffffffull || bb >= 0x7fffffffull) return VQA_EARG;
+  G8Params p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C; p.M = M; p.N = N; p.K = K;
+  p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+  p.tiles_n = N / G8_BN; p.ntiles = (M / G8_BM) * p.tiles_n;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+#ifdef VQA_ABLATION
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+#endif
+    attr = true;
+  }
+#ifdef VQA_ABLATION
+  const int np3 = vqa_env_int("VQA_G4_NP3", 8);
+  if (np3 == 4) { hipLaunchKernelGGL(gemm4w_kernel<4>, dim3(p.ntiles), dim3(256), G8_LDS, st, p); VQA_LAUNCH_CHECK(); return VQA_OK; }
+  if (np3 == 12) { hipLaunchKernelGGL(gemm4w_kernel<12>, dim3(p.ntiles), dim3(256), G8_LDS, st, p); VQA_LAUNCH_CHECK(); return VQA_OK; }
+  if (np3 == 16) { hipLaunchKernelGGL(gemm4w_kernel<16>, dim3(p.ntiles), dim3(256), G8_LDS, st, p); VQA_LAUNCH_CHECK(); return VQA_OK; }
+#endif
+  hipLaunchKernelGGL(gemm4w_kernel<8>, dim3(p.ntiles), dim3(256), G8_LDS, st, p);
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
 int vqa_gemm8p(const void* A, const void* B, void* C, int M, int N, int K, hipStream_t st) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || M % G8_BM || N % G8_BN || K % G8_BK) return VQA_EARG;
   const size_t ab = (size_t)M * K * 2, bb = (size_t)N * K * 2;
