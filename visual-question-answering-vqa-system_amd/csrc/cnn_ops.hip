@@ -1103,7 +1103,10 @@ int vqa_bn_apply_acc(int dtype, const void* y, const unsigned long long* acc, co
   const size_t rows = (size_t)B * HW;
   const int lanes_r = 256 / (C / VEC);
   int g1 = row_grid(rows, lanes_r);
-  if (g1 > 2048) g1 = 2048;                    // the per-workgroup coefficient prologue is amortised over >= ~4 passes
+  // every workgroup finalizes all C channels in its prologue (R replicas x 2 planes x 2 sums of 8-byte loads + fp64 per channel): with 2048
+  // workgroups the prologues read more bytes than the stage-4 tensor holds.  tools/bn_grid_sweep.py, B = 512: 1024 (plain) / 512 (+ residual)
+  // workgroups are 3 .. 18 % faster than 2048 at every stage; 256 loses the latency cover again
+  { const int cap = vqa_env_int("VQA_BN_GRID", res ? 512 : 1024); if (g1 > cap) g1 = cap; }
   dim3 grid(g1);
   int rpc = 0;
   const double inv_count = 1.0 / count, unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
@@ -1126,7 +1129,7 @@ int vqa_bn_apply_acc(int dtype, const void* y, const unsigned long long* acc, co
 #undef BN_ACC
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
-int vqa_bn_bwd_blocks(long long rows) { long long g = (rows + 63) / 64; return (int)(g > 768 ? 768 : (g < 1 ? 1 : g)); }
+int vqa_bn_bwd_blocks(long long rows) { long long g = (rows + 63) / 64; const int cap = vqa_env_int("VQA_BNR_GRID", rows < 65536 ? 256 : 512); return (int)(g > cap ? cap : (g < 1 ? 1 : g)); }
 // slab: [vqa_bn_bwd_blocks(rows)][3][C] floats
 // acc_mode = 1: `slab` is a fixed-point accumulator unsigned long long [3*C + 1] (zeroed by the caller) instead of a float slab
 int vqa_bn_bwd_reduce(int dtype, const void* dout, const void* outact, const void* y, const float* coef, const void* y2, const float* coef2,
@@ -1160,7 +1163,7 @@ int vqa_bn_bwd_apply_acc(int dtype, const void* dout, const void* outact, const 
   if (self_mask && (y2 || outact)) return VQA_EARG;
   const size_t rows = (size_t)numel / C;
   int grid = row_grid(rows, 256 / (C / VEC));
-  if (grid > 2048) grid = 2048;
+  { const int cap = vqa_env_int("VQA_BNB_GRID", 512); if (grid > cap) grid = cap; }     // (prologue amortisation, as vqa_bn_apply_acc: -4 .. -20 % against 2048)
   const size_t shm = (size_t)(y2 ? 6 : 3) * C * sizeof(float);
   const double inv_count = 1.0 / count;
 #define BWD_ACC(TT, S, D) hipLaunchKernelGGL((bn_bwd_apply_acc_kernel<TT, S, D>), dim3(grid), dim3(256), shm, st, (const TT*)dout, (const TT*)outact, \
