@@ -110,6 +110,7 @@ class HipEngine:
         # 12.31 forward only, 12.33 backward only (tools/ab_fusions.py, three alternations on one box; a second box: 12.73 -> 12.64)
         self.conv8p_n_multiple = 128
         self.conv8p_bwd_n_multiple = 128
+        self.pack_off_main = True                 # begin_step's backward operands (transposed weights, stem helper) are packed on the weight-gradient stream
         self.hoist_cross = True                   # cross-attention: layer 0's query projection beside the CNN, layers >= 1's K / V path (fwd + bwd) on the text stream
         self.use_c64p_epi = True                  # stage-1 conv1 data gradients (identity addend + masks) on the 8-wave patch kernel
         self.fuse_hand_reduce = False             # ... and the previous block's bn2 (+ shortcut BN) backward sums in the epilogue of conv1's data gradient:
@@ -223,9 +224,21 @@ class HipEngine:
         """Refresh the working copies of the weights (one cast of the whole flat buffer in bf16 mode)."""
         self._wt = {}
         self._stem_fcoef = None
+        self._pack_ev = None
         if for_backward:                          # inference (no tape) needs neither the transposed weights nor the stem helper
-            self._stem_fcoef = self._make_stem_fcoef() if self._wt_plan else None    # only once a backward has been seen
-            self._pack_planned()
+            # Both are BACKWARD operands: on the weight-gradient stream (idle until the backward starts) they no longer sit in front of
+            # the stem on the main stream (one 43 us pack launch + five small torch launches per step); backward() waits for the event
+            s2 = self.side2 if (self.pack_off_main and self.two_streams and self.side2 is not None and self._wt_plan) else None
+            if s2 is not None:
+                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())     # the parameters are final (optimizer step) on this stream
+                s2.wait_event(ev)
+                with torch.cuda.stream(s2):
+                    self._stem_fcoef = self._make_stem_fcoef()
+                    self._pack_planned()
+                    self._pack_ev = torch.cuda.Event(); self._pack_ev.record(s2)
+            else:
+                self._stem_fcoef = self._make_stem_fcoef() if self._wt_plan else None    # only once a backward has been seen
+                self._pack_planned()
         if self.dtype == torch.bfloat16:
             if self.wsrc is self.flat or self.wsrc.numel() != self.flat.numel():
                 self.wsrc = torch.empty(self.flat.numel(), device=self.flat.device, dtype=torch.bfloat16)
@@ -900,6 +913,9 @@ class HipEngine:
         cfg, T = self.cfg, self.dtype
         training = tape["training"]
         B = tape["B"]
+        if getattr(self, "_pack_ev", None) is not None:             # the transposed data-gradient operands / stem helper of begin_step
+            torch.cuda.current_stream().wait_event(self._pack_ev)
+            self._pack_ev = None
         self._deferred = []                       # (a backward that raised must not leak its held-back launches into this one)
         self._keep = []                           # tensors read on a side stream: released after the join at the end of backward
         self._wgq = []
