@@ -250,6 +250,7 @@ def _run(args, real_stdout):
     if rank == 0:
         K.PROFILE = []
         K.PROFILE_VARIANTS = []
+        K.PROFILE_STAGED = {}
     trainer.step(*data)
     torch.cuda.synchronize()
     trainer.engine.two_streams = was
@@ -313,6 +314,13 @@ def _run(args, real_stdout):
                 "step_algorithmic_bytes": round(step_bytes),
                 "step_algorithmic_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
                 "step_frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK, 4)}
+        staged = K.PROFILE_STAGED.get(name)
+        if staged:
+            # the K loop of an LDS-DMA tile is priced by the bytes a K tile stages: every such kernel measured on this hardware -- this repo's
+            # and hipBLASLt's at 8192^3 -- lands at 39-47 GB/s of ingest per CU (profiles/r04_conv8p_direct.txt)
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            roof["lds_dma_ingest"] = {"staged_bytes_per_launch": round(staged / n), "flop_per_staged_byte": round(fl / staged, 1),
+                                      "GBps_per_cu": round(staged / tt / 1e9 / ncu, 1), "observed_ceiling_GBps_per_cu": [39, 47], "cus": ncu}
     if use_dist:
         dist.barrier()
 

@@ -20,6 +20,7 @@ LOADER_NHWC, LOADER_STEM = 0, 1
 # launch stream and append (kernel symbol, algorithmic FLOPs, start event, end event, algorithmic bytes).
 PROFILE = None
 PROFILE_VARIANTS = []        # (symbol, variant label, FLOPs, start event, end event) of launches whose symbol covers several code paths
+PROFILE_STAGED = {}      # symbol -> bytes staged through LDS-DMA by its profiled launches (conv8p)
 
 # HBM-bound entries (no FLOPs worth counting): algorithmic bytes of one call from its C-ABI argument list -- the tensors the op
 # must read and write once; recorded as ("hbm:<class>:<entry>", 0, e0, e1, bytes) while PROFILE is a list.
@@ -258,6 +259,10 @@ def conv8p(x, w, B, H, W, C, N, *, transposed=0, stride=1, stats_acc=None, out=N
         #  PROFILE_VARIANTS lets bench.py show the two groups of launches apart)
         PROFILE_VARIANTS.append((sym, "with epilogue inputs" if (addend is not None or outmask is not None or bnred is not None) else "plain",
                                  2.0 * out.shape[0] * N * 9 * C, e0, e1))
+        # bytes the launch stages through LDS-DMA (tiles x K tiles x (tile rows + tile columns) x 128): what prices its K loop
+        bmp, bn = (224, 256) if N % 256 == 0 else (448, 128)
+        rpt = bmp * 7 // 8 if out.shape[0] % (bmp * 7 // 8) == 0 else bmp
+        PROFILE_STAGED[sym] = PROFILE_STAGED.get(sym, 0) + (-(-out.shape[0] // rpt)) * (N // bn) * (9 * C // 64) * (bmp + bn) * 128
         PROFILE.append((sym,
                         2.0 * out.shape[0] * N * 9 * C, e0, e1,
                         (B * H * W * C + out.shape[0] * N * (1 + sum(t is not None for t in (addend, addmask, outmask, bn_y, bn_y2))) + N * 9 * C) * 2))
