@@ -316,11 +316,13 @@ def _run(args, real_stdout):
                 "step_frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK, 4)}
         staged = K.PROFILE_STAGED.get(name)
         if staged:
-            # the K loop of an LDS-DMA tile is priced by the bytes a K tile stages: every such kernel measured on this hardware -- this repo's
-            # and hipBLASLt's at 8192^3 -- lands at 39-47 GB/s of ingest per CU (profiles/r04_conv8p_direct.txt)
+            # bytes the dominant kernel stages through LDS-DMA and the per-CU rate that makes.  NOT its bound: with every piece moving 1/64 of its
+            # bytes (same instructions, waits, barriers) the launches are only 9-16 % faster, and without MFMAs the loop still takes 72-78 % of its
+            # time (profiles/r04_conv8p_diag.txt): the K loop is priced by its instruction / barrier skeleton
             ncu = torch.cuda.get_device_properties(dev).multi_processor_count
             roof["lds_dma_ingest"] = {"staged_bytes_per_launch": round(staged / n), "flop_per_staged_byte": round(fl / staged, 1),
-                                      "GBps_per_cu": round(staged / tt / 1e9 / ncu, 1), "observed_ceiling_GBps_per_cu": [39, 47], "cus": ncu}
+                                      "GBps_per_cu": round(staged / tt / 1e9 / ncu, 1), "cus": ncu,
+                                      "bound_by_these_bytes": False}
     if use_dist:
         dist.barrier()
 

@@ -34,6 +34,11 @@ for name, C, H in (("s2 128->128 28", 128, 28), ("s3 256->256 14", 256, 14), ("s
     for dbg in (0, 1, 2, 3, 4, 7):
         os.environ["VQA_C8P_DBG"] = str(dbg)
         row.append(timeit(lambda: K.conv8p(x, w, B, H, H, C, C, transposed=1)))
+    row2 = []
+    for dbg in (8, 16, 24, 28):              # 8 / 16: every A / B piece moves ONE lane's 16 bytes (same instructions, waits and barriers; 1/64 of the bytes)
+        os.environ["VQA_C8P_DBG"] = str(dbg)
+        row2.append(timeit(lambda: K.conv8p(x, w, B, H, H, C, C, transposed=1)))
+    print(f"{name}  LDS-DMA bytes: A pieces one lane {row2[0]:6.1f} us | B pieces one lane {row2[1]:6.1f} | both {row2[2]:6.1f} | both, no MFMA {row2[3]:6.1f}", flush=True)
     os.environ["VQA_C8P_DBG"] = "0"
     print(f"{name}  data gradient: as shipped {row[0]:6.1f} us | A from one line {row[1]:6.1f} | B from one line {row[2]:6.1f} | both {row[3]:6.1f} | "
           f"no MFMA {row[4]:6.1f} | no MFMA, both from one line {row[5]:6.1f}", flush=True)

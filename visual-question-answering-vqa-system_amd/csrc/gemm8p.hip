@@ -334,7 +334,7 @@ struct C8Params {
   // BatchNorm sharing g -> the third row, sum g * xhat(bn_y2) (what bn_bwd_reduce_kernel<false, DUAL> leaves)
   int bn_selfmask; const bf16_t* bn_y2; const float* bn_coef2;
   int M, N, K, B, H, W, C, transposed, rpt, tiles_n, ntiles, cpk_shift;
-  int dbg;   // VQA_C8P_DBG, -DVQA_ABLATION builds only (WRONG results, timing diagnostics): 1 every A piece of a half-tile re-fetches the first one's source, 2 the same for B, 4 no MFMAs
+  int dbg;   // VQA_C8P_DBG, -DVQA_ABLATION builds only (WRONG results, timing diagnostics): 1 every A piece of a half-tile re-fetches the first one's source, 2 the same for B, 4 no MFMAs, 8 / 16 every A / B piece moves one lane's 16 bytes only
   int Ho, Wo, stride;                 // output map (= H, W for stride 1); forward convs also run with stride 2 (the stage-entry 3x3 / 2 convs)
   unsigned x_bytes, w_bytes;
 };
@@ -420,6 +420,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
       for (int h = 0; h < nk; ++h)
 #ifdef VQA_ABLATION
+        if (!(p.dbg & 8) || lane == 0)      // 8: every piece moves ONE lane's 16 bytes (same instruction count and waits, 1/64 of the bytes)
         dma16_g8(rsX, base + (unsigned)((w * nk + h) * 1024), okt ? voffA[(p.dbg & 1) ? k0 : k0 + h] : OOB_G8, okt ? cc * 128 : 0);
 #else
         dma16_g8(rsX, base + (unsigned)((w * nk + h) * 1024), okt ? voffA[k0 + h] : OOB_G8, okt ? cc * 128 : 0);   // (scalar offset: wave-uniform)
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
         const bool okp = okt && r0 < G::B_ROWS;
         const int col = (r0 / 32) * 64 + (r0 % 32) + (which == 3 ? 32 : 0);
 #ifdef VQA_ABLATION
+        if (!(p.dbg & 16) || lane == 0)     // 16: the same for the B pieces
         dma16_g8(rsW, base + (unsigned)(pc * 1024), okp ? ((pc & 1) ? voffB1 : voffB0) : OOB_G8, okp ? ((n0 + ((p.dbg & 2) ? 0 : col)) * p.K + t * G8_BK) * 2 : 0);
 #else
         dma16_g8(rsW, base + (unsigned)(pc * 1024), okp ? ((pc & 1) ? voffB1 : voffB0) : OOB_G8, okp ? ((n0 + col) * p.K + t * G8_BK) * 2 : 0);
