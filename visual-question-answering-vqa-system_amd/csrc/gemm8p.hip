@@ -106,9 +106,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(G8Params p) {
 
 #define G8_RD(dst, which, off) dst = *reinterpret_cast<const bf16x8*>(smem + (d * 4 + (which)) * G8_HALF + (off))
 #define G8_BAR() __builtin_amdgcn_s_barrier()
+// (k half OUTERMOST: the two MFMAs of an accumulator are 6-8 instructions apart.  With kk innermost hipcc emitted tmp = mfma(.., acc);
+//  acc = mfma(.., tmp): every second MFMA waited for the one in front of it)
 #define G8_MFMA_R(AF, BFR, MI, NJ, I0, I1)                                                                  \
-  _Pragma("unroll") for (int i = (I0); i < (I1); ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)        \
-      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                      \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                          \
+    _Pragma("unroll") for (int i = (I0); i < (I1); ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)      \
           acc[(MI) + i][(NJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFR[j][kk], AF[i][kk], acc[(MI) + i][(NJ) + j], 0, 0, 0)
 #define G8_WAIT() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 // one phase's compute segment
