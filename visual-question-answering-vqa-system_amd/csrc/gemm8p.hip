@@ -360,6 +360,22 @@ struct C8Geo {
   static_assert(LDS <= 160 * 1024 && RG * 2 * BN * 4 <= LDS && 2 * BN <= 512, "LDS budget");
 };
 
+#ifdef VQA_ABLATION
+// In-kernel stamps (VQA_C8P_DBG & 32, diagnostic build only; cdna_hip_programming.md section 7): s_memtime at three points of every phase -- MFMA
+// segment start (behind the mid barrier and the fragment wait), MFMA segment end (all issued), behind the end barrier -- summed per point over the K
+// loop in scalar registers; waves of workgroup 0 leave their 12 sums here.  Read the SHARES, not the length (each stamp costs ~40 cycles and drains LDS).
+__device__ unsigned g_c8p_stamps[8 * 12];
+#define C8_STAMP(IDX)                                                                                              \
+  if (p.dbg & 32) {                                                                                                \
+    unsigned long long tt_;                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    st_acc[IDX] += (unsigned)tt_ - st_prev; st_prev = (unsigned)tt_;                                               \
+  }
+#else
+#define C8_STAMP(IDX)
+#endif
 template <int WM, int WN>
 __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   using G = C8Geo<WM, WN>;
@@ -479,6 +495,10 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) C8_RD_AT(a0[i][kk], 0, ra0 + i * 2048 + sk[kk]);
 
+#ifdef VQA_ABLATION
+  unsigned st_prev = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (p.dbg & 32) { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory"); st_prev = (unsigned)t0_; }
+#endif
   for (int t = 0; t < nkt; ++t) {
     const int d = t & 1;
     // ---------------- P1: rows 0-63 of the wave x columns 0-31
@@ -490,8 +510,11 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     C8_WAIT();                                                      // B second (t) landed -> read in P2
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    C8_STAMP(0);
     C8_COMPUTE(a0, b0, 0, 0, 4);
+    C8_STAMP(1);
     G8_BAR();
+    C8_STAMP(2);
     // ---------------- P2: rows 0-63 x columns 32-63
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -501,8 +524,11 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     C8_WAIT();                                                      // A second (t) landed -> read in P3
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    C8_STAMP(3);
     C8_COMPUTE(a0, b1, 0, 2, 4);
+    C8_STAMP(4);
     G8_BAR();
+    C8_STAMP(5);
     // ---------------- P3: rows 64-111 x columns 32-63
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -512,8 +538,11 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     C8_WAIT();                                                      // A first (t + 1) landed -> read in P4
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    C8_STAMP(6);
     C8_COMPUTE(a1, b1, 4, 2, 3);
+    C8_STAMP(7);
     G8_BAR();
+    C8_STAMP(8);
     // ---------------- P4: rows 64-111 x columns 0-31; the A-first fragments of the NEXT K tile
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -523,10 +552,19 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     C8_WAIT();                                                      // B first (t + 1) landed -> read in P1 of the next K tile
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    C8_STAMP(9);
     C8_COMPUTE(a1, b0, 4, 0, 3);
+    C8_STAMP(10);
     G8_BAR();
+    C8_STAMP(11);
   }
 #undef C8_RD_AT
+#ifdef VQA_ABLATION
+  if ((p.dbg & 32) && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) g_c8p_stamps[w * 12 + i] = st_acc[i];
+  }
+#endif
   if (grp == 0) G8_BAR();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the out-of-range tail pieces have written their zeros
   G8_BAR();
@@ -739,6 +777,10 @@ int vqa_gemm8p(const void* A, const void* B, void* C, int M, int N, int K, hipSt
   hipLaunchKernelGGL(gemm8p_kernel, dim3(p.ntiles), dim3(512), G8_LDS, st, p);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
+#ifdef VQA_ABLATION
+// diagnostic builds only: the stamp sums of the last vqa_conv8p launch with VQA_C8P_DBG & 32 (8 waves x 12 points, cycles summed over the K loop)
+int vqa_conv8p_stamps(unsigned* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c8p_stamps), sizeof(unsigned) * 96); }
+#endif
 // 1: vqa_conv8p takes the shape (3x3 / stride 1 / pad 1, NHWC bf16, C a power-of-two multiple of 64, N a multiple of 128)
 int vqa_conv8p_ok(int B, int H, int W, int C, int N) {      // (H, W: the INPUT map)
   if (B <= 0 || H <= 0 || W <= 0 || H > 16383 || W > 16383 || C < 64 || (C & (C - 1)) || N <= 0 || N % 128) return 0;
