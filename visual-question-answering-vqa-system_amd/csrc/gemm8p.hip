@@ -39,6 +39,17 @@ __device__ __forceinline__ void dma16_g8(i32x4_g8 rs, unsigned lds_addr, int vof
   soff = __builtin_amdgcn_readfirstlane(soff);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_addr), "s"(soff) : "memory");
 }
+// the same with M0 already holding the LDS base of the first piece of a group: piece h of the group lands at M0 + OFF (the instruction offset is
+// added to BOTH addresses, so the caller's vector offset carries -OFF)
+template <int OFF>
+__device__ __forceinline__ void dma16_g8_off(i32x4_g8 rs, int voff, int soff) {
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(voff), "s"(rs), "s"(soff), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void set_m0_g8(unsigned lds_addr) {
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_addr) : "memory");
+}
 }  // namespace
 
 struct G8Params {
@@ -364,7 +375,7 @@ struct C8Geo {
 // In-kernel stamps (VQA_C8P_DBG & 32, diagnostic build only; cdna_hip_programming.md section 7): s_memtime at three points of every phase -- MFMA
 // segment start (behind the mid barrier and the fragment wait), MFMA segment end (all issued), behind the end barrier -- summed per point over the K
 // loop in scalar registers; waves of workgroup 0 leave their 12 sums here.  Read the SHARES, not the length (each stamp costs ~40 cycles and drains LDS).
-__device__ unsigned g_c8p_stamps[8 * 12];
+__device__ unsigned g_c8p_stamps[8 * 20];
 #define C8_STAMP(IDX)                                                                                              \
   if (p.dbg & 32) {                                                                                                \
     unsigned long long tt_;                                                                                        \
@@ -373,8 +384,17 @@ __device__ unsigned g_c8p_stamps[8 * 12];
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     st_acc[IDX] += (unsigned)tt_ - st_prev; st_prev = (unsigned)tt_;                                               \
   }
+#define C8_STAMP2(IDX)                                                                                             \
+  if (p.dbg & 64) {                                                                                                \
+    unsigned long long tt_;                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt_)::"memory");                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    st_acc[IDX] += (unsigned)tt_ - st_prev; st_prev = (unsigned)tt_;                                               \
+  }
 #else
 #define C8_STAMP(IDX)
+#define C8_STAMP2(IDX)
 #endif
 template <int WM, int WN>
 __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
@@ -398,6 +418,13 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   const int dr = lane >> 3, dc = lane & 7;
   const int slot_e = (dc ^ (dr >> 1)) << 4, slot_o = (dc ^ (dr >> 1) ^ 4) << 4;       // source slot of an even / odd piece (LDS row bit 3)
   const int HW = p.Ho * p.Wo;
+#ifndef VQA_ABLATION
+  // ONE M0 write per half-tile: the pieces of a wave's group land at M0 + 1024 h through the instruction offset, which is added to the
+  // memory address too -- the descriptors start 4 KB below the tensors and the vector offsets carry + 4096 - 1024 h (never negative)
+  const unsigned long long xs = xa - 4096ull, ws_ = wa - 4096ull;
+  const i32x4_g8 rsXs = {(int)(unsigned)xs, (int)((unsigned)(xs >> 32) & 0xffffu), (int)(p.x_bytes + 4096u), 0x00020000};
+  const i32x4_g8 rsWs = {(int)(unsigned)ws_, (int)((unsigned)(ws_ >> 32) & 0xffffu), (int)(p.w_bytes + 4096u), 0x00020000};
+#endif
 
   // ---- this lane's staged A rows: piece pc = w * N + h of A first (h < N_AF) and A second (h < N_AS); decoded once
   constexpr int NA = G::N_AF + G::N_AS;
@@ -415,6 +442,9 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     if (R < p.rpt && m < p.M) {
       const int b = m / HW, rem = m - b * HW, oh = (rem / p.Wo) * p.stride, ow = (rem - (rem / p.Wo) * p.Wo) * p.stride;   // input pixel of tap (1, 1)
       pixb[k] = ((b * p.H + oh) * p.W + ow) * p.C * 2 + slot;
+#ifndef VQA_ABLATION
+      pixb[k] += 4096 - 1024 * (second ? k - G::N_AF : k);
+#endif
       ohw[k] = (oh << 16) | ow;
     } else { pixb[k] = 0; ohw[k] = (int)0xc0000000; }                // oh = -16384: every tap fails the range test
   }
@@ -435,13 +465,19 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
           voffA[k] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? pixb[k] + dpix : OOB_G8;
         }
       }
+#ifdef VQA_ABLATION
 #pragma unroll
       for (int h = 0; h < nk; ++h)
-#ifdef VQA_ABLATION
         if (!(p.dbg & 8) || lane == 0)      // 8: every piece moves ONE lane's 16 bytes (same instruction count and waits, 1/64 of the bytes)
         dma16_g8(rsX, base + (unsigned)((w * nk + h) * 1024), okt ? voffA[(p.dbg & 1) ? k0 : k0 + h] : OOB_G8, okt ? cc * 128 : 0);
-#else
-        dma16_g8(rsX, base + (unsigned)((w * nk + h) * 1024), okt ? voffA[k0 + h] : OOB_G8, okt ? cc * 128 : 0);   // (scalar offset: wave-uniform)
+#endif
+#ifndef VQA_ABLATION
+      set_m0_g8(base + (unsigned)(w * nk * 1024));
+      const int sof = okt ? cc * 128 : 0;                            // (scalar offset: wave-uniform)
+      if (nk > 0) dma16_g8_off<0>(rsXs, okt ? voffA[k0] : OOB_G8, sof);
+      if (nk > 1) dma16_g8_off<1024>(rsXs, okt ? voffA[k0 + 1] : OOB_G8, sof);
+      if (nk > 2) dma16_g8_off<2048>(rsXs, okt ? voffA[k0 + 2] : OOB_G8, sof);
+      if (nk > 3) dma16_g8_off<3072>(rsXs, okt ? voffA[k0 + 3] : OOB_G8, sof);
 #endif
     } else {
 #pragma unroll
@@ -453,7 +489,11 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
         if (!(p.dbg & 16) || lane == 0)     // 16: the same for the B pieces
         dma16_g8(rsW, base + (unsigned)(pc * 1024), okp ? ((pc & 1) ? voffB1 : voffB0) : OOB_G8, okp ? ((n0 + ((p.dbg & 2) ? 0 : col)) * p.K + t * G8_BK) * 2 : 0);
 #else
-        dma16_g8(rsW, base + (unsigned)(pc * 1024), okp ? ((pc & 1) ? voffB1 : voffB0) : OOB_G8, okp ? ((n0 + col) * p.K + t * G8_BK) * 2 : 0);
+        if (h == 0) set_m0_g8(base + (unsigned)(pc * 1024));
+        const int vo = okp ? ((pc & 1) ? voffB1 : voffB0) + 4096 - 1024 * h : OOB_G8, so = okp ? ((n0 + col) * p.K + t * G8_BK) * 2 : 0;
+        if (h == 0) dma16_g8_off<0>(rsWs, vo, so);
+        else if (h == 1) dma16_g8_off<1024>(rsWs, vo, so);
+        else dma16_g8_off<2048>(rsWs, vo, so);
 #endif
       }
     }
@@ -496,19 +536,41 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     for (int kk = 0; kk < 2; ++kk) C8_RD_AT(a0[i][kk], 0, ra0 + i * 2048 + sk[kk]);
 
 #ifdef VQA_ABLATION
-  unsigned st_prev = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (p.dbg & 32) { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory"); st_prev = (unsigned)t0_; }
+  unsigned st_prev = 0, st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (p.dbg & 224) { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory"); st_prev = (unsigned)t0_; }
 #endif
   for (int t = 0; t < nkt; ++t) {
     const int d = t & 1;
     // ---------------- P1: rows 0-63 of the wave x columns 0-31
+#ifdef VQA_ABLATION
+    unsigned long long q0_ = 0, q1_ = 0, q2_ = 0, q3_ = 0;           // dbg & 128: raw s_memtime inside P1's load segment (no waits of their own; read behind the segment's own lgkmcnt(0))
+    if (p.dbg & 128) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(q0_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD(b0[j][kk], rb0 + j * 2048 + sk[kk]);
+#ifdef VQA_ABLATION
+    if (p.dbg & 128) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(q1_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
     stage(3, t + 1);
+#ifdef VQA_ABLATION
+    if (p.dbg & 128) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(q2_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
+    C8_STAMP2(12);
     C8_WAIT();                                                      // B second (t) landed -> read in P2
+    C8_STAMP2(16);
+#ifdef VQA_ABLATION
+    if (p.dbg & 128) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(q3_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
     G8_BAR();
+#ifdef VQA_ABLATION
+    if (p.dbg & 128) {
+      unsigned long long q4_;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q4_), "+s"(q0_), "+s"(q1_), "+s"(q2_), "+s"(q3_)::"memory");
+      st_acc[0] += (unsigned)(q1_ - q0_); st_acc[1] += (unsigned)(q2_ - q1_); st_acc[2] += (unsigned)(q3_ - q2_); st_acc[3] += (unsigned)(q4_ - q3_);
+    }
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     C8_STAMP(0);
     C8_COMPUTE(a0, b0, 0, 0, 4);
@@ -521,7 +583,9 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD(b1[j][kk], rb1 + j * 2048 + sk[kk]);
     stage(1, t + 1);
+    C8_STAMP2(13);
     C8_WAIT();                                                      // A second (t) landed -> read in P3
+    C8_STAMP2(17);
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     C8_STAMP(3);
@@ -535,7 +599,9 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD(a1[i][kk], ra1 + i * 2048 + sk[kk]);
     stage(0, t + 2);
+    C8_STAMP2(14);
     C8_WAIT();                                                      // A first (t + 1) landed -> read in P4
+    C8_STAMP2(18);
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     C8_STAMP(6);
@@ -549,7 +615,9 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD_AT(a0[i][kk], d ^ 1, ra0 + i * 2048 + sk[kk]);
     stage(2, t + 2);
+    C8_STAMP2(15);
     C8_WAIT();                                                      // B first (t + 1) landed -> read in P1 of the next K tile
+    C8_STAMP2(19);
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     C8_STAMP(9);
@@ -560,9 +628,9 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   }
 #undef C8_RD_AT
 #ifdef VQA_ABLATION
-  if ((p.dbg & 32) && blockIdx.x == 0 && lane == 0) {
+  if ((p.dbg & 224) && blockIdx.x == 0 && lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) g_c8p_stamps[w * 12 + i] = st_acc[i];
+    for (int i = 0; i < 20; ++i) g_c8p_stamps[w * 20 + i] = st_acc[i];
   }
 #endif
   if (grp == 0) G8_BAR();
@@ -779,7 +847,7 @@ int vqa_gemm8p(const void* A, const void* B, void* C, int M, int N, int K, hipSt
 }
 #ifdef VQA_ABLATION
 // diagnostic builds only: the stamp sums of the last vqa_conv8p launch with VQA_C8P_DBG & 32 (8 waves x 12 points, cycles summed over the K loop)
-int vqa_conv8p_stamps(unsigned* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c8p_stamps), sizeof(unsigned) * 96); }
+int vqa_conv8p_stamps(unsigned* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c8p_stamps), sizeof(unsigned) * 160); }
 #endif
 // 1: vqa_conv8p takes the shape (3x3 / stride 1 / pad 1, NHWC bf16, C a power-of-two multiple of 64, N a multiple of 128)
 int vqa_conv8p_ok(int B, int H, int W, int C, int N) {      // (H, W: the INPUT map)
