@@ -449,9 +449,10 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     } else { pixb[k] = 0; ohw[k] = (int)0xc0000000; }                // oh = -16384: every tap fails the range test
   }
   const int voffB0 = dr * p.K * 2 + slot_e, voffB1 = dr * p.K * 2 + slot_o;
-  auto stage = [&](int which, int t) {                               // which: 0 A first, 1 A second, 2 B first, 3 B second
+  // inr_c: compile-time promise that K tile t exists (the steady loop; the last two K tiles and the prologue test t < nkt and stage zeros beyond)
+  auto stage_c = [&](auto inr_c, int which, int t) __attribute__((always_inline)) {      // which: 0 A first, 1 A second, 2 B first, 3 B second
     const unsigned base = lds0 + (unsigned)((t & 1) * G::BUF + (which == 0 ? G::OFF_AF : which == 1 ? G::OFF_AS : which == 2 ? G::OFF_BF : G::OFF_BS));
-    const bool okt = t < nkt;
+    const bool okt = decltype(inr_c)::value ? true : t < nkt;
     if (which < 2) {                                                 // A: gathered pixels of tap (t >> cpk_shift), channel chunk t & (cpk - 1)
       const int tap = t >> p.cpk_shift, cc = t & ((1 << p.cpk_shift) - 1);
       const int k0 = which ? G::N_AF : 0, nk = which ? G::N_AS : G::N_AF;
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
       }
     }
   };
+  auto stage = [&](int which, int t) __attribute__((always_inline)) { stage_c(std::false_type{}, which, t); };
 
   const int fl = (li >> 1) & 7;
   const unsigned sk[2] = {(unsigned)((g ^ fl) << 4), (unsigned)((g ^ fl ^ 4) << 4)};       // slot of k half kk
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
   unsigned st_prev = 0, st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (p.dbg & 224) { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory"); st_prev = (unsigned)t0_; }
 #endif
-  for (int t = 0; t < nkt; ++t) {
+  auto ktile = [&](auto inr_c, const int t) __attribute__((always_inline)) {
     const int d = t & 1;
     // ---------------- P1: rows 0-63 of the wave x columns 0-31
 #ifdef VQA_ABLATION
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
 #ifdef VQA_ABLATION
     if (p.dbg & 128) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(q1_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
 #endif
-    stage(3, t + 1);
+    stage_c(inr_c, 3, t + 1);
 #ifdef VQA_ABLATION
     if (p.dbg & 128) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(q2_)::"memory"); __builtin_amdgcn_sched_barrier(0); }
 #endif
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD(b1[j][kk], rb1 + j * 2048 + sk[kk]);
-    stage(1, t + 1);
+    stage_c(inr_c, 1, t + 1);
     C8_STAMP2(13);
     C8_WAIT();                                                      // A second (t) landed -> read in P3
     C8_STAMP2(17);
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD(a1[i][kk], ra1 + i * 2048 + sk[kk]);
-    stage(0, t + 2);
+    stage_c(inr_c, 0, t + 2);
     C8_STAMP2(14);
     C8_WAIT();                                                      // A first (t + 1) landed -> read in P4
     C8_STAMP2(18);
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) C8_RD_AT(a0[i][kk], d ^ 1, ra0 + i * 2048 + sk[kk]);
-    stage(2, t + 2);
+    stage_c(inr_c, 2, t + 2);
     C8_STAMP2(15);
     C8_WAIT();                                                      // B first (t + 1) landed -> read in P1 of the next K tile
     C8_STAMP2(19);
@@ -625,7 +627,11 @@ __global__ __launch_bounds__(512, 2) void conv8p_kernel(C8Params p) {
     C8_STAMP(10);
     G8_BAR();
     C8_STAMP(11);
-  }
+  };
+  // the steady loop stages K tiles that exist (no range test, no select per piece); the last two K tiles stage the out-of-range tail
+  int t_ = 0;
+  for (; t_ + 2 < nkt; ++t_) ktile(std::true_type{}, t_);
+  for (; t_ < nkt; ++t_) ktile(std::false_type{}, t_);
 #undef C8_RD_AT
 #ifdef VQA_ABLATION
   if ((p.dbg & 224) && blockIdx.x == 0 && lane == 0) {
