@@ -66,7 +66,9 @@ def test_whole_bench_main_with_two_ranks_on_one_gpu_over_gloo():
     nflat = LY.flat_size(LY.build_entries(O.full_config()))
     assert out["config"]["bytes_allreduced_per_step"] == 4 * nflat + 4     # every bucket of the flat gradient + the bad-target counter
     roof = out["roofline"]
-    assert roof["frac"] > 0 and roof["hbm_classes"]["bn"]["GBps"] > 0      # the all-rank profiling steps ran (collectives matched)
+    # the all-rank profiling steps ran (collectives matched).  Two ranks share one GPU and the gloo reducer stalls the streams on the
+    # host, so a launch's event interval can hold a whole all-reduce: only presence is asserted (frac is rounded to 4 digits)
+    assert roof["avg_launch_us"] > 0 and roof["kernel_time_ms_per_step"] > 0 and roof["hbm_classes"]["bn"]["GBps"] > 0
     assert out["cpu_baseline"] is None and out["extras"] is None           # N > 1: rank 0 skips the single-rank extras
 
 
