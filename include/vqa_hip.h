@@ -36,6 +36,13 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
               int stats_mode /* 0: stats = float slab [mtiles][2][N]; 1: stats = fixed-point accumulator (see vqa_bn_apply_acc) */,
               hipStream_t stream);
+/* Data gradient of a Linear whose INPUT was relu(+dropout(p)) of the previous Linear, with the consumer's mask applied by the producer
+ * (round 4): dx[M][Kin] = (dz[M][N] * wt[Kin][N]^T + addend) * (outact > 0) / (1 - drop_p); the keep scale multiplies the
+ * value already rounded to the compute dtype, so dx is bit-equal to vqa_igemm followed by vqa_bias_act_bwd(outact, p).  Replaces the
+ * autograd nodes of nn.ReLU + nn.Dropout between two nn.Linear (models/text_encoder.py:309-317 FeedForward, models/cross_attention.py:257-263,
+ * models/vqa_model.py:74-82 AnswerHead).  wt = the [Kin][N] transposed weight (vqa_pack_transpose).  outact required. */
+int vqa_linear_dgrad_act(int dtype, const void* dz, const void* wt, void* dx, const void* addend, const void* outact, float drop_p,
+                         int M, int Kin, int N, hipStream_t stream);
 /* dw[N][Kw] += dy[M][N]^T * gather(x)[M][Kw], split over the M pixels.
  * With a workspace (`ws`, caller-owned scratch of >= the ws_floats vqa_wgrad_plan reports; contents undefined afterwards) every
  * split writes its fp32 tile to its own slab and a second launch adds the slabs to dw in a FIXED order: dw is bit-reproducible,
@@ -262,6 +269,11 @@ int vqa_attention_bwd_mfma(const void* dctx, int ldc, const void* q, const void*
  * Replaces the argmax/topk + .cpu() + .item() of VQAAccuracy.update (utils/metrics.py:55-94); ties resolve to the lowest index. */
 int vqa_accuracy_update(const float* logits, const long long* targets, unsigned long long* counters, int B, int N, hipStream_t stream);
 /* masked mean over tokens (models/fusion.py:303-313, models/text_encoder.py:522-527) */
+/* both masked means of the fusion tail in one launch (round 4): out[B][2D] = [mean_m(x0) | mean_m(x1)] with the same mask, and the
+ * matching backward dx{0,1}[b][l][:] = dcat[b][{0,D}:] * m[b][l] / cnt (models/fusion.py:281-296); per-element arithmetic of
+ * vqa_masked_pool_fwd / _bwd (bit-equal). */
+int vqa_masked_pool_pair_fwd(int dtype, const void* x0, const void* x1, const float* mask, void* out, int B, int L, int D, hipStream_t stream);
+int vqa_masked_pool_pair_bwd(int dtype, const void* dcat, const float* mask, void* dx0, void* dx1, int B, int L, int D, hipStream_t stream);
 int vqa_masked_pool_fwd(int dtype, const void* x, const float* mask, void* out, int ldo, int col0, int B, int L, int D, hipStream_t stream);
 int vqa_masked_pool_bwd(int dtype, const void* dpool, int ldo, int col0, const float* mask, const void* addend, void* dx,
                         int B, int L, int D, hipStream_t stream);

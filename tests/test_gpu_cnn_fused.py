@@ -250,6 +250,36 @@ def test_bf16_step_with_and_without_the_round4_kernels():
     assert torch.equal(l_c, l_ref) and torch.equal(g_c, g_ref)
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_bf16_step_with_and_without_the_activation_mask_in_the_dgrad_epilogue(dropout):
+    """fuse_act_dgrad (round 4): the ReLU(+dropout) backward between two Linears (4 text FFNs, 2 cross-attention FFNs, 2 answer-head
+    pairs) applied by the data-gradient GEMM's epilogue, the bias column sums taken off the chain.  Same logits; every gradient is
+    bit-equal except the 8 bias gradients in front of those activations, which are now the column sums of the STORED (bf16) gradient
+    instead of the fp32 value before its rounding: identical without dropout (keep scale 1), within 2e-3 of their norm with it."""
+    from oracle import vqa_oracle as O
+    from _pkg import sub as _sub
+    cfg = O.full_config(dropout=dropout, answer_dropout=0.3 if dropout else 0.0)
+    sd = O.init_state_dict(cfg, 6, jitter=True)
+    batch = [t.to(DEV) for t in O.synthetic_batch(16, seed=78)]
+    l_ref, g_ref = _bf16_step(cfg, sd, batch)
+    l_a, g_a = _bf16_step(cfg, sd, batch, fuse_act_dgrad=False)
+    assert torch.equal(l_a, l_ref)
+    if dropout == 0.0:
+        assert torch.equal(g_a, g_ref)
+        return
+    LY = _sub("layout")
+    entries = LY.build_entries(cfg)
+    moved = 0
+    for e in entries:
+        a, r = g_a[e.offset: e.offset + e.numel], g_ref[e.offset: e.offset + e.numel]
+        if torch.equal(a, r):
+            continue
+        moved += 1
+        assert e.name.endswith(".bias") and e.name not in ("answer_head.classifier.6.bias",), e.name
+        assert float((a - r).norm() / r.norm()) < 2e-3, e.name
+    assert 1 <= moved <= 8, moved
+
+
 @pytest.mark.parametrize("log2_scale", [16, 24])
 def test_bf16_backward_is_linear_in_the_loss_scale(log2_scale):
     """The whole bf16 backward under a power-of-two loss scale (GradScaler's 2^16 ... ): every bf16 rounding and every fixed-point sum is

@@ -110,6 +110,32 @@ def test_linear_fwd_bwd_epilogues(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("drop_p", [0.0, 0.1, 0.3])
+@pytest.mark.parametrize("case", [(40, 256, 1024), (80, 1024, 256), (17, 512, 256), (512, 256, 1000), (2000, 256, 256), (10240, 1024, 256)])
+def test_linear_dgrad_with_the_activation_mask_in_its_epilogue(case, drop_p, dtype):
+    """vqa_linear_dgrad_act (round 4): the data gradient of a Linear that leaves with the ReLU(+dropout) backward of the layer in front
+    applied == vqa_igemm followed by vqa_bias_act_bwd, BIT-equal (the keep scale multiplies the value already rounded to the compute
+    dtype), and == the torch formula.  Shapes: FFN fc2 -> fc1 (models/text_encoder.py:309-317), answer head (models/vqa_model.py:74-82)."""
+    K, L = sub("kernels"), sub("_lib")
+    M, Kin, N = case                                    # dz [M][N], W [N][Kin], h = the masked layer's output [M][Kin]
+    g = torch.Generator().manual_seed(M + 3 * N)
+    dz = _round(torch.randn(M, N, generator=g), dtype).to(DEV, dtype)
+    w = _round(torch.randn(N, Kin, generator=g) / N ** 0.5, dtype)
+    h = torch.relu(torch.randn(M, Kin, generator=g))
+    h = _round(h * (torch.rand(M, Kin, generator=g) > drop_p), dtype).to(DEV, dtype)      # out > 0 encodes ReLU and dropout
+    wt = K.pack_transpose(w.to(DEV).view(N, 1, Kin), dtype)
+    fused = K.linear_dgrad_act(dz, wt, M, Kin, N, dtype=dtype, outact=h, drop_p=drop_p)
+    dh, _, _ = K.igemm(dz, wt, M, Kin, N, K.linear_geom(M, N), dtype=dtype)
+    two = torch.empty_like(dh)
+    L.call("vqa_bias_act_bwd", L.dt(dtype), dh.data_ptr(), h.data_ptr(), two.data_ptr(), None, M, Kin, float(drop_p), 0, None, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two)
+    ref = (dz.float().cpu() @ w) * (h.float().cpu() > 0) / (1.0 - drop_p)
+    assert _relerr(fused.float().cpu(), ref) < _tol(dtype)
+    assert (fused[h <= 0] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_stem_conv_fwd_wgrad(dtype):
     K = sub("kernels")
     B, H = 2, 40

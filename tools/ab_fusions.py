@@ -7,7 +7,7 @@ import bench
 pkg = importlib.import_module("visual-question-answering-vqa-system_amd")
 M = pkg.load_dropin()
 data = bench.synth_batch(512, torch.device("cuda", 0), 1234)
-CASES = [("default", {}), ("backward operands packed on the main stream", dict(pack_off_main=False)), ("handed bn2 reduce in the conv1 dgrad epilogue", dict(fuse_hand_reduce=True)), ("cross-attention q / kv paths not hoisted", dict(hoist_cross=False)), ("no c64p epilogue variant (igemm 128x64)", dict(use_c64p_epi=False)), ("no bn1 reduce in the dgrad epilogue", dict(fuse_bn1_reduce=False)), ("conv8p not for stage 2 (igemm there)", dict(conv8p_n_multiple=256, conv8p_bwd_n_multiple=256)), ("no conv8p (igemm 128x128)", dict(use_conv8p=False)), ("conv8p forward only", dict(use_conv8p_bwd=False)), ("no fuse_bn_conv (a1 stored)", dict(fuse_bn_conv=False)), ("no bn_finalize fusion", dict(fuse_bn_finalize=False)), ("no se_pool", dict(fuse_se_pool=False)),
+CASES = [("default", {}), ("no act mask in the dgrad epilogue", dict(fuse_act_dgrad=False)), ("no chain trim (column sums / text add on the chain)", dict(chain_trim=False)), ("neither", dict(chain_trim=False, fuse_act_dgrad=False)), ("backward operands packed on the main stream", dict(pack_off_main=False)), ("handed bn2 reduce in the conv1 dgrad epilogue", dict(fuse_hand_reduce=True)), ("cross-attention q / kv paths not hoisted", dict(hoist_cross=False)), ("no c64p epilogue variant (igemm 128x64)", dict(use_c64p_epi=False)), ("no bn1 reduce in the dgrad epilogue", dict(fuse_bn1_reduce=False)), ("conv8p not for stage 2 (igemm there)", dict(conv8p_n_multiple=256, conv8p_bwd_n_multiple=256)), ("no conv8p (igemm 128x128)", dict(use_conv8p=False)), ("conv8p forward only", dict(use_conv8p_bwd=False)), ("no fuse_bn_conv (a1 stored)", dict(fuse_bn_conv=False)), ("no bn_finalize fusion", dict(fuse_bn_finalize=False)), ("no se_pool", dict(fuse_se_pool=False)),
          ("no se_bnred", dict(fuse_se_bnred=False)), ("none of the three", dict(fuse_se_pool=False, fuse_se_bnred=False, fuse_bn_finalize=False))]
 NC = int(os.environ.get("AB_CASES", "4"))
 if os.environ.get("AB_ONLY"):          # e.g. AB_ONLY=0,3: the cases with these indices

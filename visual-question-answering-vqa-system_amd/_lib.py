@@ -24,6 +24,7 @@ SIGNATURES = {
     "vqa_igemm_mtiles": [I, I, I],
     "vqa_igemm_variant": [I] * 15,
     "vqa_igemm": [I, I, P, P, P, P, P, P, P, P] + [I] * 15 + [F, ULL, I, P],
+    "vqa_linear_dgrad_act": [I, P, P, P, P, P, F, I, I, I, P],
     "vqa_wgrad_plan": [I] * 11 + [P, P, P, P, P],
     "vqa_wgrad": [I, I, P, P, P] + [I] * 13 + [P, LL, P],
     "vqa_pack_rows": [I, P, P, I, I, I, P],
@@ -92,6 +93,8 @@ SIGNATURES = {
     "vqa_attention_bwd_mfma": [P, I, P, P, P, I, I, I, P, P, P, P, I, I, I, I, I, I, I, I, F, ULL, P],
     "vqa_masked_pool_fwd": [I, P, P, P, I, I, I, I, I, P],
     "vqa_masked_pool_bwd": [I, P, I, I, P, P, P, I, I, I, P],
+    "vqa_masked_pool_pair_fwd": [I, P, P, P, P, I, I, I, P],
+    "vqa_masked_pool_pair_bwd": [I, P, P, P, P, I, I, I, P],
     "vqa_gate_fwd": [I, P, P, P, I, I, P],
     "vqa_gate_bwd": [I, P, P, P, P, P, I, I, P],
     "vqa_add": [I, P, P, P, LL, P],

@@ -20,6 +20,7 @@ struct IGemmParams {
   const void* a; const void* w; void* out;
   const float* bias; const void* addend; const void* addmask; float* stats;
   const void* outmask;       // != nullptr: out = (... + addend) * (outmask > 0): the consumer's ReLU mask applied by the producer
+  float out_scale;           // with outmask: kept elements are multiplied by this (1 / (1 - p) of a ReLU + dropout whose output IS the mask)
   int stats_mode;            // 0: stats is a float slab [tiles][2][N]; 1: a fixed-point accumulator u64 [vqa_bn_acc_words(2, N)] (common.h acc_add_fixed)
   int M, N, Kp, Kw;          // Kp: reduction length rounded up to BK; Kw: weight row length (elements)
   int B, H, W, C;            // source tensor (NHWC; NCHW fp32 image for the stem loader)
@@ -664,6 +665,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
         if (omT) {                                     // data gradient handed to the previous block already masked by ITS ReLU
 #pragma unroll
           for (int j = 0; j < VEC; ++j) if (!(ov[i].get(j) > 0.f)) v.set(j, 0.f);
+          if (p.out_scale != 1.f) {                    // (uniform) the bf16 value times the keep scale, as vqa_bias_act_bwd forms it
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v.set(j, v.get(j) * p.out_scale);
+          }
         }
         stg16(outT + off, v);
       } else {
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void igemm_kernel(IGemmParams p) {   
           float x = v.get(j);
           if (addT) { float a = to_f<T>(addT[off + j]); x += (!mskT || to_f<T>(mskT[off + j]) > 0.f) ? a : 0.f; }
           if (p.relu == 2 && x < 0.f) x = 0.f;
-          if (omT && !(to_f<T>(omT[off + j]) > 0.f)) x = 0.f;
+          if (omT) x = (to_f<T>(omT[off + j]) > 0.f) ? (p.out_scale != 1.f ? to_f<T>(from_f<T>(x)) * p.out_scale : x) : 0.f;
           outT[off + j] = from_f<T>(x);
         }
       }
@@ -1555,8 +1560,34 @@ int vqa_igemm_variant(int dtype, int loader, int M, int N, int Kw, int B, int H,
   return igemm_variant(p, loader, dtype != 0);
 }
 
+static int igemm_entry(int dtype, int loader, const void* a, const void* w, void* out, const float* bias,
+              const void* addend, const void* addmask, const void* outmask, float out_scale, float* stats,
+              int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
+              int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
+              int stats_mode, hipStream_t st);
+
 int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, const float* bias,
               const void* addend, const void* addmask, const void* outmask, float* stats,
+              int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
+              int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
+              int stats_mode, hipStream_t st) {
+  return igemm_entry(dtype, loader, a, w, out, bias, addend, addmask, outmask, 1.f, stats, M, N, Kw, B, H, W, C, Ho, Wo, R, S, stride, pad,
+                     transposed, relu, drop_p, drop_seed, stats_mode, st);
+}
+
+// dx[M][Kin] = (dz[M][N] W) * (outact > 0) / (1 - drop_p): the data gradient of a Linear whose INPUT was relu(+dropout(p)) of the previous
+// Linear -- the producer applies the consumer's mask (outact > 0 encodes both) and the keep scale 1 / (1 - p) to the bf16 value, bit-equal
+// to vqa_bias_act_bwd on the stored gradient (models/text_encoder.py:309-317, models/vqa_model.py:74-82 backward).
+int vqa_linear_dgrad_act(int dtype, const void* dz, const void* wt, void* dx, const void* addend, const void* outact, float drop_p,
+                         int M, int Kin, int N, hipStream_t st) {
+  if (!outact || !(drop_p >= 0.f && drop_p < 1.f)) return VQA_EARG;
+  const float out_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;      // the same float expression as bias_act_bwd's keep scale
+  return igemm_entry(dtype, LOADER_NHWC, dz, wt, dx, nullptr, addend, nullptr, outact, out_scale, nullptr, M, Kin, N, M, 1, 1, N, 1, 1, 1, 1, 1, 0,
+                     0, 0, 0.f, 0ull, 0, st);
+}
+
+static int igemm_entry(int dtype, int loader, const void* a, const void* w, void* out, const float* bias,
+              const void* addend, const void* addmask, const void* outmask, float out_scale, float* stats,
               int M, int N, int Kw, int B, int H, int W, int C, int Ho, int Wo,
               int R, int S, int stride, int pad, int transposed, int relu, float drop_p, unsigned long long drop_seed,
               int stats_mode, hipStream_t st) {
@@ -1574,6 +1605,7 @@ int vqa_igemm(int dtype, int loader, const void* a, const void* w, void* out, co
   if (stats && stats_mode && (M + 63) / 64 > VQA_ACC_MAX_PARTS) return VQA_EARG;   // one partial per M tile: the fixed-point total must not wrap (common.h)
   IGemmParams p;
   p.a = a; p.w = w; p.out = out; p.bias = bias; p.addend = addend; p.addmask = addmask; p.stats = stats; p.outmask = outmask;
+  p.out_scale = out_scale;
   p.stats_mode = stats_mode;
   p.M = M; p.N = N; p.Kw = Kw; p.Kp = (Kw + BK - 1) / BK * BK;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
@@ -1604,7 +1636,7 @@ int vqa_dgrad_s2(int dtype, const void* dy, const void* dyd, const void* wt, voi
   const int VEC = dtype ? 8 : 4, BK = dtype ? 64 : 32;
   if (!dy || !wt || !out || (Ho & 1) || (Wo & 1) || C % BK || N % VEC || R > 3 || R < 1) return VQA_EARG;
   IGemmParams p;
-  p.a = dy; p.a2 = dyd; p.w = wt; p.out = out; p.bias = nullptr; p.addend = nullptr; p.addmask = nullptr; p.stats = nullptr; p.outmask = nullptr;
+  p.a = dy; p.a2 = dyd; p.w = wt; p.out = out; p.bias = nullptr; p.addend = nullptr; p.addmask = nullptr; p.stats = nullptr; p.outmask = nullptr; p.out_scale = 1.f;
   p.stats_mode = 0;
   p.N = N; p.Kw = R * R * C + (dyd ? C : 0); p.Kp = p.Kw; p.M = B * Ho * Wo;
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.R = R; p.S = R; p.stride = 2; p.pad = pad;

@@ -533,6 +533,38 @@ __global__ void masked_pool_bwd_kernel(const T* __restrict__ dpool, int ldo, int
   }
 }
 
+// Both masked means of the fusion tail in one launch (models/fusion.py:281-296: attended queries and text features pooled with the
+// same mask into cat = [att | txt]): blockIdx.y picks the tensor; the arithmetic per element is masked_pool_fwd_kernel's.
+template <typename T>
+__global__ void masked_pool_pair_fwd_kernel(const T* __restrict__ x0, const T* __restrict__ x1, const float* __restrict__ mask, T* __restrict__ out,
+                                            int L, int D) {
+  const int b = blockIdx.x, which = blockIdx.y;
+  const T* __restrict__ x = which ? x1 : x0;
+  float cnt = 0.f;
+  for (int l = 0; l < L; ++l) cnt += mask ? mask[b * L + l] : 1.f;
+  cnt = fmaxf(cnt, 1.f);
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += to_f<T>(x[((size_t)b * L + l) * D + d]) * (mask ? mask[b * L + l] : 1.f);
+    out[(size_t)b * 2 * D + which * D + d] = from_f<T>(s / cnt);
+  }
+}
+// ... and both backward broadcasts: dx{0,1}[b][l][d] = dcat[b][{0,D}+d] * m[b][l] / cnt
+template <typename T>
+__global__ void masked_pool_pair_bwd_kernel(const T* __restrict__ dcat, const float* __restrict__ mask, T* __restrict__ dx0, T* __restrict__ dx1,
+                                            int L, int D) {
+  const int b = blockIdx.x, which = blockIdx.y;
+  T* __restrict__ dx = which ? dx1 : dx0;
+  float cnt = 0.f;
+  for (int l = 0; l < L; ++l) cnt += mask ? mask[b * L + l] : 1.f;
+  cnt = fmaxf(cnt, 1.f);
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const float g = to_f<T>(dcat[(size_t)b * 2 * D + which * D + d]);
+    for (int l = 0; l < L; ++l)
+      dx[((size_t)b * L + l) * D + d] = from_f<T>(g * (mask ? mask[b * L + l] : 1.f) / cnt);
+  }
+}
+
 // gate: g = sigmoid(z); fused = g*att + (1-g)*txt, cat = [att | txt]  (models/fusion.py:160-166)
 template <typename T>
 __global__ void gate_fwd_kernel(const T* __restrict__ z, const T* __restrict__ cat, T* __restrict__ fused, int B, int D) {
@@ -879,6 +911,18 @@ int vqa_attention_bwd(int dtype, const void* dctx, int ldc, const void* q, const
 int vqa_masked_pool_fwd(int dtype, const void* x, const float* mask, void* out, int ldo, int col0, int B, int L, int D, hipStream_t st) {
   DT(hipLaunchKernelGGL(masked_pool_fwd_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)x, mask, (float*)out, ldo, col0, L, D),
      hipLaunchKernelGGL(masked_pool_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)x, mask, (bf16_t*)out, ldo, col0, L, D));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_masked_pool_pair_fwd(int dtype, const void* x0, const void* x1, const float* mask, void* out, int B, int L, int D, hipStream_t st) {
+  if (!x0 || !x1 || !out || B <= 0 || L <= 0 || D <= 0) return VQA_EARG;
+  DT(hipLaunchKernelGGL(masked_pool_pair_fwd_kernel<float>, dim3(B, 2), dim3(256), 0, st, (const float*)x0, (const float*)x1, mask, (float*)out, L, D),
+     hipLaunchKernelGGL(masked_pool_pair_fwd_kernel<bf16_t>, dim3(B, 2), dim3(256), 0, st, (const bf16_t*)x0, (const bf16_t*)x1, mask, (bf16_t*)out, L, D));
+  VQA_LAUNCH_CHECK(); return VQA_OK;
+}
+int vqa_masked_pool_pair_bwd(int dtype, const void* dcat, const float* mask, void* dx0, void* dx1, int B, int L, int D, hipStream_t st) {
+  if (!dcat || !dx0 || !dx1 || B <= 0 || L <= 0 || D <= 0) return VQA_EARG;
+  DT(hipLaunchKernelGGL(masked_pool_pair_bwd_kernel<float>, dim3(B, 2), dim3(256), 0, st, (const float*)dcat, mask, (float*)dx0, (float*)dx1, L, D),
+     hipLaunchKernelGGL(masked_pool_pair_bwd_kernel<bf16_t>, dim3(B, 2), dim3(256), 0, st, (const bf16_t*)dcat, mask, (bf16_t*)dx0, (bf16_t*)dx1, L, D));
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 int vqa_masked_pool_bwd(int dtype, const void* dpool, int ldo, int col0, const float* mask, const void* addend, void* dx, int B, int L, int D, hipStream_t st) {

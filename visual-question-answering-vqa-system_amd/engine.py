@@ -91,6 +91,8 @@ class HipEngine:
         self._foldq2 = []
         self.defer_folds = True
         self.bias_offpath = False
+        self.chain_trim = False                   # backward: pure bias column sums of the head / gate / projector and the text-gradient add leave the main-stream chain (measured neutral: 12.11 vs 12.09 ms, off)
+        self.fuse_act_dgrad = True                # ReLU(+dropout) backward of a Linear -> ReLU -> Dropout -> Linear pair applied by the data-gradient GEMM's epilogue; the bias column sums leave the chain
         self.use_c64_fwd = False                  # 4-wave stage-1 patch kernel for forward / data gradient (superseded by the 8-wave one)
         self.use_c64p = True                      # 8-wave weights-resident stage-1 conv kernel
         self.fuse_se_pool = True                  # SE global-average-pool sums leave the last block's bn_apply (one read of the stage output less)
@@ -412,6 +414,21 @@ class HipEngine:
         elif q:                                   # side outputs: off the data-gradient chain (second side stream, like the conv dW)
             self._off_path([t for j in q for t in (j[0], j[1])], lambda: K.wgrad_group(q, dtype=self.dtype))
 
+    def _lin_act_bwd(self, dz, x_in, wname, bname_prev, G, p):
+        """Backward of `x_in = dropout(relu(linear_prev(.) + bias_prev)); y = linear(x_in)` from dz = dL/dy down to the gradient at
+        linear_prev's output: dW += dz^T x_in, d(pre-activation) = (dz W) * (x_in > 0) / (1 - p) out of ONE launch on the data-gradient
+        chain (vqa_linear_dgrad_act; x_in > 0 encodes both masks as in vqa_bias_act_bwd), bias_prev's gradient = its column sums taken
+        off the chain.  Bit-equal to _lin_bwd + _act_bwd."""
+        e = self.E[wname]
+        N, Kin = e.shape[0], e.shape[1]
+        if not self.fuse_act_dgrad or N % 8 or Kin % 8:
+            return self._act_bwd(self._lin_bwd(dz, x_in, wname, G), x_in, bname_prev, G, p, 0)
+        M = dz.shape[0]
+        self._wgrad_linear(dz, x_in, LY.mat_of(G, e), M, N, Kin)
+        dpre = K.linear_dgrad_act(dz, self.Wt(wname), M, Kin, N, dtype=self.dtype, outact=x_in, drop_p=p)
+        self._act_bwd(dpre, None, bname_prev, G, 0.0, 0, off_chain=True)
+        return dpre
+
     def _lin_bwd(self, dz, x_in, wname, G, need_dx=True, addend=None):
         """dW += dz^T x ; returns dx = dz W (+ addend)."""
         e = self.E[wname]
@@ -436,7 +453,7 @@ class HipEngine:
         dx, _, _ = K.igemm(dz, self.Wt(wname), M, Kin, N, K.linear_geom(M, N), dtype=self.dtype, addend=addend)
         return dx
 
-    def _act_bwd(self, dout, outact, bname, G, p, seed):
+    def _act_bwd(self, dout, outact, bname, G, p, seed, off_chain=False):
         """Gradient at the pre-activation of `linear(+bias)(+relu)(+dropout)`; accumulates the bias gradient."""
         M, N = dout.shape
         need_dz = (outact is not None) or p > 0.0
@@ -454,7 +471,7 @@ class HipEngine:
                 call("vqa_bias_act_bwd", dt(dout), ptr(dout), ptr(outact), ptr(dz), ptr(dbias), M, N, float(p), int(seed), ptr(ws), defer)
                 if defer:                  # the bias gradient is only read by the optimizer: fold it with the rest of the segment
                     (self._foldq if on_chain else self._foldq2).append((ws, 0, K.L.count("vqa_bias_act_bwd_fold_rows", dt(dout), M, N), N, N, dbias, N, None))
-            on_chain = need_dz or not self.bias_offpath
+            on_chain = need_dz or not (self.bias_offpath or off_chain)
             if on_chain:
                 launch()
             else:                          # a pure column sum (no mask, no dropout): a side output, off the data-gradient chain
@@ -736,8 +753,7 @@ class HipEngine:
             probs_all.append(rec["probs"])
             q = rec["out"]
         cat = torch.empty((Bt, 2 * d), device=dev, dtype=T)
-        call("vqa_masked_pool_fwd", dt(T), ptr(q), ptr(maskf), ptr(cat), 2 * d, 0, Bt, L, d)
-        call("vqa_masked_pool_fwd", dt(T), ptr(enc), ptr(maskf), ptr(cat), 2 * d, d, Bt, L, d)
+        call("vqa_masked_pool_pair_fwd", dt(T), ptr(q), ptr(enc), ptr(maskf), ptr(cat), Bt, L, d)      # [attended | text] means, one launch
         fused_pre = torch.empty((Bt, d), device=dev, dtype=T)
         z = None
         if cfg["use_gating"]:
@@ -843,8 +859,7 @@ class HipEngine:
         d = heads * hd
         attn, fc1, fc2 = rec["attn"], rec["fc1"], rec["fc2"]
         dz2 = self._act_bwd(dout, None, fc2 + ".bias", G, p, rec["s2"])
-        dh = self._lin_bwd(dz2, rec["h"], fc2 + ".weight", G)
-        dz1 = self._act_bwd(dh, rec["h"], fc1 + ".bias", G, p, rec["s1"])
+        dz1 = self._lin_act_bwd(dz2, rec["h"], fc2 + ".weight", fc1 + ".bias", G, p)
         dnf = self._lin_bwd(dz1, rec["nf"], fc1 + ".weight", G)
         dx1 = self._ln_bwd(dnf, rec["x1"], rec["norm_f"], rec["stf"], G, addend=dout)
         dzo = self._act_bwd(dx1, None, None, G, p, rec["so"])
@@ -944,11 +959,9 @@ class HipEngine:
 
         # ---- head
         hdr = tape["head"]; c = "answer_head.classifier"
-        dz = self._act_bwd(dl, None, c + ".6.bias", G, 0.0, 0)
-        dh2 = self._lin_bwd(dz, hdr["h2"], c + ".6.weight", G)
-        dz = self._act_bwd(dh2, hdr["h2"], c + ".3.bias", G, hdr["p"], hdr["s2"])
-        dh1 = self._lin_bwd(dz, hdr["h1"], c + ".3.weight", G)
-        dz = self._act_bwd(dh1, hdr["h1"], c + ".0.bias", G, hdr["p"], hdr["s1"])
+        dz = self._act_bwd(dl, None, c + ".6.bias", G, 0.0, 0, off_chain=self.chain_trim)
+        dz = self._lin_act_bwd(dz, hdr["h2"], c + ".6.weight", c + ".3.bias", G, hdr["p"])
+        dz = self._lin_act_bwd(dz, hdr["h1"], c + ".3.weight", c + ".0.bias", G, hdr["p"])
         dfused = self._lin_bwd(dz, hdr["fused"], c + ".0.weight", G)
         seg("answer_head")
 
@@ -959,14 +972,13 @@ class HipEngine:
         if cfg["use_gating"]:
             dzg = torch.empty_like(pr["z"])
             call("vqa_gate_bwd", dt(T), ptr(dfp), ptr(pr["z"]), ptr(pr["cat"]), ptr(dzg), ptr(dcat), B, d)
-            dzg = self._act_bwd(dzg, None, "fusion.gate.gate.0.bias", G, 0.0, 0)
+            dzg = self._act_bwd(dzg, None, "fusion.gate.gate.0.bias", G, 0.0, 0, off_chain=self.chain_trim)
             dcat = self._lin_bwd(dzg, pr["cat"], "fusion.gate.gate.0.weight", G, addend=dcat)
         else:
             dcat[:, :d] = dfp; dcat[:, d:] = dfp
         dq = torch.empty_like(pr["q"])
-        call("vqa_masked_pool_bwd", dt(T), ptr(dcat), 2 * d, 0, ptr(pr["maskf"]), None, ptr(dq), B, L, d)
         denc = torch.empty_like(pr["enc"])
-        call("vqa_masked_pool_bwd", dt(T), ptr(dcat), 2 * d, d, ptr(pr["maskf"]), None, ptr(denc), B, L, d)
+        call("vqa_masked_pool_pair_bwd", dt(T), ptr(dcat), ptr(pr["maskf"]), ptr(dq), ptr(denc), B, L, d)
         # ---- cross-attention layers (reverse); image-token gradient accumulates across layers
         dimg, ev_img = None, None
         side_ok = self.hoist_cross and self.two_streams and self.side is not None
@@ -975,13 +987,16 @@ class HipEngine:
                                                     addend_event=ev_img)
         if ev_img is not None:                                    # (a single layer never takes the side path; kept for safety)
             torch.cuda.current_stream().wait_event(ev_img)
-        # dq is now the gradient wrt text features through the query path
-        call("vqa_add", dt(T), ptr(denc), ptr(dq), ptr(denc), denc.numel())
+        # dq is now the gradient wrt text features through the query path: it joins the pooled-text gradient on the text stream below
+        # (only the text encoder's backward reads the sum; the projector / CNN chain does not wait for it)
+        add_on_side = self.chain_trim and self.two_streams and self.side is not None
+        if not add_on_side:
+            call("vqa_add", dt(T), ptr(denc), ptr(dq), ptr(denc), denc.numel())
         # ---- projector
         pj = "fusion.image_projector.projection"; rp = tape["proj"]
         dpos = self._gslice(G, "fusion.image_projector.position_embedding")
         dpz = self._ln_bwd(dimg, rp["pz"], pj + ".1", rp["st"], G, p=rp["p"], seed=rp["seed"], dadd=dpos, period=rp["ntok"])
-        dpz = self._act_bwd(dpz, None, pj + ".0.bias", G, 0.0, 0)
+        dpz = self._act_bwd(dpz, None, pj + ".0.bias", G, 0.0, 0, off_chain=self.chain_trim)
         dfeat = self._lin_bwd(dpz, rp["feat"], pj + ".0.weight", G)
         seg("fusion")
 
@@ -991,8 +1006,10 @@ class HipEngine:
         if use_side:
             evf = torch.cuda.Event(); evf.record(main)
             self.side.wait_event(evf)
-            self._keep.append(denc)                       # allocated on main, consumed on the side stream: alive until the join below
+            self._keep.extend([denc, dq])                 # allocated on main, consumed on the side stream: alive until the join below
         with torch.cuda.stream(self.side if use_side else main):
+            if add_on_side:
+                call("vqa_add", dt(T), ptr(denc), ptr(dq), ptr(denc), denc.numel())
             fn = tape["final_norm"]
             dx = self._ln_bwd(denc, fn["x"], "text_encoder.final_norm", fn["st"], G)
             for rec in reversed(tape["tlayers"]):

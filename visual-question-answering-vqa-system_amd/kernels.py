@@ -53,6 +53,8 @@ HBM_BYTES = {
     "vqa_embed_bwd": ("token", lambda a: a[4] * a[5] * _ES(a[0]) + a[6] * a[5] * 4),
     "vqa_masked_pool_fwd": ("token", lambda a: a[6] * a[7] * a[8] * _ES(a[0])),
     "vqa_masked_pool_bwd": ("token", lambda a: a[7] * a[8] * a[9] * _ES(a[0])),
+    "vqa_masked_pool_pair_fwd": ("token", lambda a: 2 * a[5] * a[6] * a[7] * _ES(a[0])),
+    "vqa_masked_pool_pair_bwd": ("token", lambda a: 2 * a[5] * a[6] * a[7] * _ES(a[0])),
     "vqa_attention_fwd_mfma": ("attention", lambda a: (a[10] * (a[12] + 2 * a[13]) * a[9] + a[10] * a[12] * a[9]) * 2 + a[10] * a[11] * a[12] * a[13] * 4),
     "vqa_attention_bwd_mfma": ("attention", lambda a: 2 * (a[15] * (a[17] + 2 * a[18]) * a[1]) * 2 + a[15] * a[17] * a[1] * 2 + a[15] * a[16] * a[17] * a[18] * 4),
     "vqa_attention_fwd": ("attention", lambda a: (a[11] * (a[13] + 2 * a[14]) * a[10] + a[11] * a[13] * a[10]) * _ES(a[0]) + a[11] * a[12] * a[13] * a[14] * 4),
@@ -401,6 +403,22 @@ def igemm(a, w, M, N, Kw, geom, *, dtype, loader=LOADER_NHWC, bias=None, addend=
         nbytes = (B * H * W * C * (4 if loader == LOADER_STEM else es)) + (M * N + N * Kw) * es
         PROFILE.append((igemm_symbol(dtype, loader, var), flops, e0, e1, nbytes))
     return out, stats, mt
+
+
+def linear_dgrad_act(dz, wt, M, Kin, N, *, dtype, outact, drop_p, addend=None):
+    """dx[M][Kin] = (dz[M][N] @ wt[Kin][N]^T + addend) * (outact > 0) / (1 - drop_p): a Linear's data gradient that leaves with the ReLU(+dropout)
+    mask of the layer in front applied (vqa_linear_dgrad_act; bit-equal to igemm followed by vqa_bias_act_bwd)."""
+    dx = torch.empty((M, Kin), device=dz.device, dtype=dtype)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vqa_linear_dgrad_act", dt(dtype), ptr(dz), ptr(wt), ptr(dx), ptr(addend), ptr(outact), float(drop_p), M, Kin, N)
+    if PROFILE is not None:
+        e1.record()
+        var = igemm_variant(dtype, LOADER_NHWC, M, Kin, N, linear_geom(M, N))
+        es = 2 if dtype == torch.bfloat16 else 4
+        PROFILE.append((igemm_symbol(dtype, LOADER_NHWC, var), 2.0 * M * N * Kin, e0, e1, (M * N + 2 * M * Kin + N * Kin) * es))
+    return dx
 
 
 _PLAN_CACHE = {}
