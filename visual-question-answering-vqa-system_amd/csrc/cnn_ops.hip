@@ -615,6 +615,30 @@ __global__ __launch_bounds__(256) void scale_kernel(const T* __restrict__ x, con
   }
 }
 
+// dhs[jr] = [hidden[jr] > 0] * sum_c z2[c] * w2[c][jr] for one sample, by the whole workgroup (round 4, third session).  w2 is [C][Cr]:
+// the first form gave a wave one jr and walked c across its lanes -- 64 different cache lines per load (stride Cr floats), 16 K line
+// requests per workgroup at C = 512 / Cr = 32, which is what made the 7 x 7 x 512 stage's SE backward take 80 us for 157 MB.  Here
+// consecutive lanes read consecutive jr (thread = (channel group g, jr), G <= 64 groups), the G partials per jr are folded in group
+// order through LDS: one writer, fixed order (bit-reproducible).  part: >= NT floats of LDS free at this point; ends with a barrier.
+__device__ __forceinline__ void se_fc2_bwd(const float* __restrict__ z2, const float* __restrict__ w2, const float* __restrict__ hidden_b,
+                                           float* __restrict__ dhs, float* __restrict__ dh_b, float* __restrict__ part, int C, int Cr, int NT) {
+  const int G = min(NT / Cr, 64);
+  const int jr = threadIdx.x % Cr, g = threadIdx.x / Cr;
+  if (g < G) {
+    float t = 0.f;
+    for (int c = g; c < C; c += G) t += z2[c] * w2[(size_t)c * Cr + jr];
+    part[g * Cr + jr] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < Cr) {
+    float t = 0.f;
+    for (int q = 0; q < G; ++q) t += part[q * Cr + threadIdx.x];
+    t = hidden_b[threadIdx.x] > 0.f ? t : 0.f;
+    dhs[threadIdx.x] = t; dh_b[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
 // SE backward, per sample: ds[c] = sum_hw dout*x ; through sigmoid / fc2 / relu / fc1 -> dz2[B][C], dh[B][Cr], dpool[B][C]
 template <typename T>
 __global__ __launch_bounds__(1024) void se_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ w1,
@@ -658,14 +682,7 @@ __global__ __launch_bounds__(1024) void se_bwd_reduce_kernel(const T* __restrict
     z2[c] = t; dz2[(size_t)b * C + c] = t;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int jr = wave; jr < Cr; jr += NT >> 6) {
-    float t = 0.f;
-    for (int c = lane; c < C; c += 64) t += z2[c] * w2[(size_t)c * Cr + jr];
-    t = wave_sum(t);
-    if (lane == 0) { t = hidden[(size_t)b * Cr + jr] > 0.f ? t : 0.f; dhs[jr] = t; dh[(size_t)b * Cr + jr] = t; }
-  }
-  __syncthreads();
+  se_fc2_bwd(z2, w2, hidden + (size_t)b * Cr, dhs, dh + (size_t)b * Cr, sh, C, Cr, NT);
   for (int c = threadIdx.x; c < C; c += NT) {
     float t = 0.f;
     for (int jr = 0; jr < Cr; ++jr) t += dhs[jr] * w1[(size_t)jr * C + c];
@@ -743,7 +760,12 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
 // (phase 2 of se_bwd_apply_kernel), so the second read of dout / x of that sample (0.4 MB ... 50 KB each) comes from the caches it
 // just filled (L2 / Infinity Cache) instead of from HBM after the whole batch has streamed through twice.  Same arithmetic in the
 // same order per element as the two-launch form: dx is bit-identical.  BNRED as in se_bwd_apply_kernel (accumulator mode only).
-template <typename T, bool BNRED>
+// NREG > 0 (round 4, third session): a thread visits the SAME (pixel, channel group) elements in both phases, so the first NREG vectors
+// of dout it reads in phase 1 stay in its registers (+ one bit per element for x > 0) and phase 2 neither re-reads dout nor x for them:
+// 7 -> 5 tensor passes where everything fits (NREG = 4: all of a 7 x 7 x 512 sample, 4 of 7 vectors at 14 x 14 x 256, 4 of 13 / 25 at stages 2 / 1; more kept vectors spill).  Loads are issued unconditionally on
+// clamped addresses (a load under a branch makes hipcc drain the queue in front of it), the arithmetic per element and its order are
+// the NREG = 0 kernel's: bit-identical dx and sums.
+template <typename T, bool BNRED, int NREG = 0>
 __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ w1,
                                                            const float* __restrict__ w2, const float* __restrict__ hidden,
                                                            const float* __restrict__ scale, float* __restrict__ dz2, float* __restrict__ dh,
@@ -761,8 +783,38 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
   float s[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  Vec16<T> dreg[NREG > 0 ? NREG : 1];
+  unsigned mbits[NREG > 0 ? (NREG + 3) / 4 : 1];          // [x > 0] of the kept vectors, 8 bits each
   {
     int p = myr;
+    if constexpr (NREG > 0) {
+      static_assert(NREG % 2 == 0 && VEC == 8, "kept vectors: pairs of 8-element vectors");
+#pragma unroll
+      for (int k = 0; k < (NREG + 3) / 4; ++k) mbits[k] = 0u;
+#pragma unroll
+      for (int i = 0; i < NREG; i += 2) {
+        const int p0 = myr + i * lanes_r, p1 = p0 + lanes_r;
+        const size_t o0 = base + (size_t)min(p0, HW - 1) * C, o1 = base + (size_t)min(p1, HW - 1) * C;
+        Vec16<T> d0 = ldg16(dout + o0), v0 = ldg16(x + o0), d1 = ldg16(dout + o1), v1 = ldg16(x + o1);
+        dreg[i] = d0; dreg[i + 1] = d1;
+        unsigned m0 = 0u, m1 = 0u;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { m0 |= (v0.get(j) > 0.f ? 1u : 0u) << j; m1 |= (v1.get(j) > 0.f ? 1u : 0u) << j; }
+        mbits[i >> 2] |= m0 << ((i & 3) * 8);
+        mbits[(i + 1) >> 2] |= m1 << (((i + 1) & 3) * 8);
+        if (p1 < HW) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) s[j] += d0.get(j) * v0.get(j) + d1.get(j) * v1.get(j);
+        } else if (p0 < HW) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) s[j] += d0.get(j) * v0.get(j);
+        }
+        // keep the PACKED vectors (4 registers each), not the 8 unpacked floats the products were formed from
+        asm volatile("" : "+v"(dreg[i].raw), "+v"(dreg[i + 1].raw));
+        if ((i & 2) != 0) __builtin_amdgcn_sched_barrier(0);     // two pairs of loads in flight at a time: hoisting all of them spills
+      }
+      p = myr + NREG * lanes_r;
+    }
     for (; p + lanes_r < HW; p += 2 * lanes_r) {
       const size_t o0 = base + (size_t)p * C, o1 = base + (size_t)(p + lanes_r) * C;
       Vec16<T> d0 = ldg16(dout + o0), v0 = ldg16(x + o0), d1 = ldg16(dout + o1), v1 = ldg16(x + o1);
@@ -790,14 +842,7 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
     z2[c] = t; dz2[(size_t)b * C + c] = t;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int jr = wave; jr < Cr; jr += NT >> 6) {
-    float t = 0.f;
-    for (int c = lane; c < C; c += 64) t += z2[c] * w2[(size_t)c * Cr + jr];
-    t = wave_sum(t);
-    if (lane == 0) { t = hidden[(size_t)b * Cr + jr] > 0.f ? t : 0.f; dhs[jr] = t; dh[(size_t)b * Cr + jr] = t; }
-  }
-  __syncthreads();
+  se_fc2_bwd(z2, w2, hidden + (size_t)b * Cr, dhs, dh + (size_t)b * Cr, sh, C, Cr, NT);
   for (int c = threadIdx.x; c < C; c += NT) {
     float t = 0.f;
     for (int jr = 0; jr < Cr; ++jr) t += dhs[jr] * w1[(size_t)jr * C + c];
@@ -812,8 +857,32 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
     sc[j] = scl[c0 + j]; dp[j] = dpl[c0 + j] * inv;
     if (BNRED) { sg[j] = sx[j] = 0.f; bmean[j] = bn_coef[2 * C + c0 + j]; binv[j] = bn_coef[3 * C + c0 + j]; }
   }
+  if constexpr (NREG > 0) {
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+      const int p = myr + i * lanes_r;
+      const size_t e = base + (size_t)min(p, HW - 1) * C;
+      Vec16<T> o, yy;
+      if constexpr (BNRED) yy = ldg16(bn_y + e);
+      const unsigned mb = mbits[i >> 2] >> ((i & 3) * 8);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float v = fmaf(dreg[i].get(j), sc[j], dp[j]);
+        if (mask_out && !((mb >> j) & 1u)) v = 0.f;
+        o.set(j, v);
+      }
+      if (p < HW) {
+        if constexpr (BNRED) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { const float g = o.get(j); sg[j] += g; sx[j] += g * (yy.get(j) - bmean[j]) * binv[j]; }
+        }
+        stg16(dx + e, o);
+      }
+      if ((i & 1) != 0) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
 #pragma unroll 2
-  for (int p = myr; p < HW; p += lanes_r) {
+  for (int p = myr + NREG * lanes_r; p < HW; p += lanes_r) {
     const size_t e = base + (size_t)p * C;
     Vec16<T> d = ldg16(dout + e), o, xm, yy;
     if (mask_out) xm = ldg16(x + e);
@@ -860,10 +929,13 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
 // dw2[c][j] += sum_b dz2[b][c]*hidden[b][j] ; dw1[j][c] += sum_b dh[b][j]*pooled[b][c]
 // A workgroup owns 8 consecutive (j, c) pairs (c fastest) and splits the batch over 32 thread slices; the slices are folded in LDS
 // in slice order, so every weight has ONE writer and a fixed summation order (bit-reproducible, no atomics, no scratch).
-__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ dz2, const float* __restrict__ hidden, const float* __restrict__ dh,
+// OUTS = 32 (round 4, third session): a wave's load covers two full 128-byte rows of dz2 / pooled instead of eight 32-byte pieces
+// (C * Cr = 16 384 outputs at the 512-channel stage: 28 -> ~10 us); same 32 slices, same fold order: the same bits as OUTS = 8.
+template <int OUTS>
+__global__ __launch_bounds__(OUTS * 32) void se_wgrad_kernel(const float* __restrict__ dz2, const float* __restrict__ hidden, const float* __restrict__ dh,
                                 const float* __restrict__ pooled, float* dw1, float* dw2, int B, int C, int Cr) {
-  const int pr = threadIdx.x & 7, q = threadIdx.x >> 3;
-  const int i = blockIdx.x * 8 + pr;
+  const int pr = threadIdx.x % OUTS, q = threadIdx.x / OUTS;
+  const int i = blockIdx.x * OUTS + pr;
   const bool live = i < C * Cr;
   const int j = live ? i / C : 0, c = live ? i - j * C : 0;
   float t2 = 0.f, t1 = 0.f;
@@ -874,17 +946,22 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
       t1 += dh[(size_t)b * Cr + j] * pooled[(size_t)b * C + c];
     }
   }
-  __shared__ float sh[2][32][8];
+  __shared__ float sh[2][32][OUTS];
   sh[0][q][pr] = t2; sh[1][q][pr] = t1;
   __syncthreads();
-  if (threadIdx.x < 16 && blockIdx.x * 8 + (threadIdx.x & 7) < C * Cr) {
-    const int which = threadIdx.x >> 3, pp = threadIdx.x & 7;
-    const int ii = blockIdx.x * 8 + pp, jj = ii / C, cc = ii - jj * C;
+  if (threadIdx.x < 2 * OUTS && blockIdx.x * OUTS + (threadIdx.x % OUTS) < C * Cr) {
+    const int which = threadIdx.x / OUTS, pp = threadIdx.x % OUTS;
+    const int ii = blockIdx.x * OUTS + pp, jj = ii / C, cc = ii - jj * C;
     float t = 0.f;
 #pragma unroll
     for (int s_ = 0; s_ < 32; ++s_) t += sh[which][s_][pp];
     if (which == 0) dw2[(size_t)cc * Cr + jj] += t; else dw1[(size_t)jj * C + cc] += t;
   }
+}
+static void launch_se_wgrad(const float* dz2, const float* hidden, const float* dh, const float* pooled, float* dw1, float* dw2, int B, int C, int Cr,
+                            hipStream_t st) {
+  if (C * Cr >= 1024) hipLaunchKernelGGL(se_wgrad_kernel<32>, dim3((C * Cr + 31) / 32), dim3(1024), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
+  else hipLaunchKernelGGL(se_wgrad_kernel<8>, dim3((C * Cr + 7) / 8), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1239,6 +1316,8 @@ int vqa_se_bwd_blocks(int dtype, int B, int HW, int C) {
   const int g = px_grid((size_t)B * HW, C, VEC);
   return g > 2048 ? 2048 : g;          // slab rows vqa_bn_bwd_finalize folds (it is sized for <= ~1k rows: 16384 rows cost it +90 us)
 }
+// measurement switch (ablation builds only): VQA_SE_NREG=0 -> the re-reading form of the per-sample SE backward
+static bool se_bwd_nreg_off() { return vqa_env_int("VQA_SE_NREG", 1) == 0; }
 // scratch floats vqa_se_bwd needs: dz2[B*C] | dh[B*Cr] | dpool[B*C]
 long long vqa_se_bwd_scratch(int dtype, int B, int HW, int C, int Cr) { (void)dtype; (void)HW; return (long long)B * (2 * C + Cr); }
 // scratch: vqa_se_bwd_scratch floats
@@ -1253,7 +1332,7 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   if ((bn_slab != nullptr) != (bn_y != nullptr) || (bn_slab != nullptr) != (bn_coef != nullptr)) return VQA_EARG;
   float* dz2 = scratch; float* dh = dz2 + (size_t)B * C; float* dpool = dh + (size_t)B * Cr;
   const int cvh = C / VEC;
-  const int nt = (1024 % cvh == 0 && (long long)HW * cvh >= 4096) ? 1024 : 256;      // threads per sample (tiny maps: 256 are plenty)
+  const int nt = (1024 % cvh == 0 && (long long)HW * cvh >= (dtype ? 2048 : 4096)) ? 1024 : 256;      // threads per sample (tiny maps: 256 are plenty; bf16 7 x 7 x 512: 1024, so that a thread keeps all its 4 vectors)
   const size_t shm = ((size_t)nt * VEC + C + Cr) * 4;
   const bool accm = (bn_acc_mode & 1) != 0;
   if (bn_slab && accm && B > VQA_ACC_MAX_PARTS) return VQA_EARG;     // one partial per sample (common.h: the fixed-point total must not wrap)
@@ -1261,10 +1340,22 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
     const size_t shm2 = ((size_t)nt * VEC + 3 * C + Cr) * 4;
 #define SE_FUSED(TT, R) hipLaunchKernelGGL((se_bwd_fused_kernel<TT, R>), dim3(B), dim3(nt), shm2, st, (const TT*)dout, (const TT*)x, w1, w2, hidden, scale, \
     dz2, dh, dpool, (TT*)dx, HW, C, Cr, mask_out, (const TT*)bn_y, bn_coef, (unsigned long long*)bn_slab)
-    if (dtype) { if (bn_slab) SE_FUSED(bf16_t, true); else SE_FUSED(bf16_t, false); }
+#define SE_FUSED_R(NR) hipLaunchKernelGGL((se_bwd_fused_kernel<bf16_t, true, NR>), dim3(B), dim3(nt), shm2, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, \
+    hidden, scale, dz2, dh, dpool, (bf16_t*)dx, HW, C, Cr, mask_out, (const bf16_t*)bn_y, bn_coef, (unsigned long long*)bn_slab)
+#define SE_FUSED_P(NR) hipLaunchKernelGGL((se_bwd_fused_kernel<bf16_t, false, NR>), dim3(B), dim3(nt), shm2, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, \
+    hidden, scale, dz2, dh, dpool, (bf16_t*)dx, HW, C, Cr, mask_out, (const bf16_t*)bn_y, bn_coef, (unsigned long long*)bn_slab)
+    const int nit = (HW + nt / cvh - 1) / (nt / cvh);          // vectors a thread visits per phase
+    const int nreg = !dtype || se_bwd_nreg_off() ? 0 : nit <= 2 ? 2 : 4;       // (8 / 12 kept vectors spill at the 128 registers a 1024-thread workgroup leaves a wave)
+    if (dtype && nreg) {
+      if (bn_slab) { if (nreg == 2) SE_FUSED_R(2); else SE_FUSED_R(4); }
+      else         { if (nreg == 2) SE_FUSED_P(2); else SE_FUSED_P(4); }
+    }
+    else if (dtype) { if (bn_slab) SE_FUSED(bf16_t, true); else SE_FUSED(bf16_t, false); }
     else { if (bn_slab) SE_FUSED(float, true); else SE_FUSED(float, false); }
+#undef SE_FUSED_R
+#undef SE_FUSED_P
 #undef SE_FUSED
-    hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 7) / 8), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
+    launch_se_wgrad(dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr, st);
     VQA_LAUNCH_CHECK(); return VQA_OK;
   }
   DT(hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, dim3(B), dim3(nt), shm, st, (const float*)dout, (const float*)x, w1, w2, hidden, scale, dz2, dh, dpool, HW, C, Cr),
@@ -1278,7 +1369,7 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
   if (dtype) { if (bn_slab) SE_APPLY(bf16_t, true); else SE_APPLY(bf16_t, false); }
   else { if (bn_slab) SE_APPLY(float, true); else SE_APPLY(float, false); }
 #undef SE_APPLY
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((C * Cr + 7) / 8), dim3(256), 0, st, dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr);
+  launch_se_wgrad(dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr, st);
   VQA_LAUNCH_CHECK(); return VQA_OK;
 }
 
