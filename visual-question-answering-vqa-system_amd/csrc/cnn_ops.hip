@@ -765,7 +765,9 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
 // 7 -> 5 tensor passes where everything fits (NREG = 4: all of a 7 x 7 x 512 sample, 4 of 7 vectors at 14 x 14 x 256, 4 of 13 / 25 at stages 2 / 1; more kept vectors spill).  Loads are issued unconditionally on
 // clamped addresses (a load under a branch makes hipcc drain the queue in front of it), the arithmetic per element and its order are
 // the NREG = 0 kernel's: bit-identical dx and sums.
-template <typename T, bool BNRED, int NREG = 0>
+// NLDS > 0: the next NLDS vectors are parked in LDS between the phases (16 bytes per thread and vector behind the scratch region;
+// one workgroup per CU is resident anyway at these register counts): 10 of a thread's 13 / 25 vectors at stages 2 / 1.
+template <typename T, bool BNRED, int NREG = 0, int NLDS = 0>
 __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ w1,
                                                            const float* __restrict__ w2, const float* __restrict__ hidden,
                                                            const float* __restrict__ scale, float* __restrict__ dz2, float* __restrict__ dh,
@@ -783,12 +785,15 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
   float s[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  constexpr int NKEEP = NREG + NLDS;
   Vec16<T> dreg[NREG > 0 ? NREG : 1];
-  unsigned mbits[NREG > 0 ? (NREG + 3) / 4 : 1];          // [x > 0] of the kept vectors, 8 bits each
+  unsigned mbits[NREG > 0 ? (NREG + 3) / 4 : 1];          // [x > 0] of the vectors kept in registers, 8 bits each
+  u32x4* dl = reinterpret_cast<u32x4*>(sh + ((blockDim.x * VEC + 3 * C + Cr + 3) & ~3));      // [NLDS][NT] parked vectors ...
+  unsigned char* dm = reinterpret_cast<unsigned char*>(dl + NLDS * blockDim.x);              // ... and their [x > 0] bytes
   {
     int p = myr;
     if constexpr (NREG > 0) {
-      static_assert(NREG % 2 == 0 && VEC == 8, "kept vectors: pairs of 8-element vectors");
+      static_assert(NREG % 2 == 0 && NLDS % 2 == 0 && VEC == 8, "kept vectors: pairs of 8-element vectors");
 #pragma unroll
       for (int k = 0; k < (NREG + 3) / 4; ++k) mbits[k] = 0u;
 #pragma unroll
@@ -813,7 +818,27 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
         asm volatile("" : "+v"(dreg[i].raw), "+v"(dreg[i + 1].raw));
         if ((i & 2) != 0) __builtin_amdgcn_sched_barrier(0);     // two pairs of loads in flight at a time: hoisting all of them spills
       }
-      p = myr + NREG * lanes_r;
+      if constexpr (NLDS > 0) {                                  // a rolled loop: unrolled, the parked vectors crowd the registers again
+#pragma unroll 1
+        for (int k = 0; k < NLDS; k += 2) {
+          const int p0 = myr + (NREG + k) * lanes_r, p1 = p0 + lanes_r;
+          const size_t o0 = base + (size_t)min(p0, HW - 1) * C, o1 = base + (size_t)min(p1, HW - 1) * C;
+          Vec16<T> d0 = ldg16(dout + o0), v0 = ldg16(x + o0), d1 = ldg16(dout + o1), v1 = ldg16(x + o1);
+          unsigned m0 = 0u, m1 = 0u;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { m0 |= (v0.get(j) > 0.f ? 1u : 0u) << j; m1 |= (v1.get(j) > 0.f ? 1u : 0u) << j; }
+          dl[k * blockDim.x + threadIdx.x] = d0.raw; dl[(k + 1) * blockDim.x + threadIdx.x] = d1.raw;
+          dm[k * blockDim.x + threadIdx.x] = (unsigned char)m0; dm[(k + 1) * blockDim.x + threadIdx.x] = (unsigned char)m1;
+          if (p1 < HW) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[j] += d0.get(j) * v0.get(j) + d1.get(j) * v1.get(j);
+          } else if (p0 < HW) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[j] += d0.get(j) * v0.get(j);
+          }
+        }
+      }
+      p = myr + NKEEP * lanes_r;
     }
     for (; p + lanes_r < HW; p += 2 * lanes_r) {
       const size_t o0 = base + (size_t)p * C, o1 = base + (size_t)(p + lanes_r) * C;
@@ -880,9 +905,29 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
       }
       if ((i & 1) != 0) __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (NLDS > 0) {
+#pragma unroll 2
+      for (int k = 0; k < NLDS; ++k) {
+        const int p = myr + (NREG + k) * lanes_r;
+        if (p >= HW) break;
+        const size_t e = base + (size_t)p * C;
+        Vec16<T> o, yy, dk;
+        if constexpr (BNRED) yy = ldg16(bn_y + e);
+        dk.raw = dl[k * blockDim.x + threadIdx.x];               // (a thread reads back only what it wrote: no barrier needed)
+        const unsigned mb = dm[k * blockDim.x + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float v = fmaf(dk.get(j), sc[j], dp[j]);
+          if (mask_out && !((mb >> j) & 1u)) v = 0.f;
+          o.set(j, v);
+          if constexpr (BNRED) { const float g = o.get(j); sg[j] += g; sx[j] += g * (yy.get(j) - bmean[j]) * binv[j]; }
+        }
+        stg16(dx + e, o);
+      }
+    }
   }
 #pragma unroll 2
-  for (int p = myr + NREG * lanes_r; p < HW; p += lanes_r) {
+  for (int p = myr + NKEEP * lanes_r; p < HW; p += lanes_r) {
     const size_t e = base + (size_t)p * C;
     Vec16<T> d = ldg16(dout + e), o, xm, yy;
     if (mask_out) xm = ldg16(x + e);
@@ -1318,6 +1363,7 @@ int vqa_se_bwd_blocks(int dtype, int B, int HW, int C) {
 }
 // measurement switch (ablation builds only): VQA_SE_NREG=0 -> the re-reading form of the per-sample SE backward
 static bool se_bwd_nreg_off() { return vqa_env_int("VQA_SE_NREG", 1) == 0; }
+static bool se_bwd_nlds_off() { return vqa_env_int("VQA_SE_NLDS", 1) == 0; }
 // scratch floats vqa_se_bwd needs: dz2[B*C] | dh[B*Cr] | dpool[B*C]
 long long vqa_se_bwd_scratch(int dtype, int B, int HW, int C, int Cr) { (void)dtype; (void)HW; return (long long)B * (2 * C + Cr); }
 // scratch: vqa_se_bwd_scratch floats
@@ -1340,20 +1386,23 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
     const size_t shm2 = ((size_t)nt * VEC + 3 * C + Cr) * 4;
 #define SE_FUSED(TT, R) hipLaunchKernelGGL((se_bwd_fused_kernel<TT, R>), dim3(B), dim3(nt), shm2, st, (const TT*)dout, (const TT*)x, w1, w2, hidden, scale, \
     dz2, dh, dpool, (TT*)dx, HW, C, Cr, mask_out, (const TT*)bn_y, bn_coef, (unsigned long long*)bn_slab)
-#define SE_FUSED_R(NR) hipLaunchKernelGGL((se_bwd_fused_kernel<bf16_t, true, NR>), dim3(B), dim3(nt), shm2, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, \
-    hidden, scale, dz2, dh, dpool, (bf16_t*)dx, HW, C, Cr, mask_out, (const bf16_t*)bn_y, bn_coef, (unsigned long long*)bn_slab)
-#define SE_FUSED_P(NR) hipLaunchKernelGGL((se_bwd_fused_kernel<bf16_t, false, NR>), dim3(B), dim3(nt), shm2, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, \
-    hidden, scale, dz2, dh, dpool, (bf16_t*)dx, HW, C, Cr, mask_out, (const bf16_t*)bn_y, bn_coef, (unsigned long long*)bn_slab)
+#define SE_FUSED_K(R_, NR, NL) do { \
+      const size_t shl = ((shm2 + 15) & ~(size_t)15) + (size_t)(NL) * nt * 17; \
+      auto kfn = se_bwd_fused_kernel<bf16_t, R_, NR, NL>; \
+      if (shl > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl); \
+      hipLaunchKernelGGL(kfn, dim3(B), dim3(nt), shl, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, hidden, scale, dz2, dh, dpool, (bf16_t*)dx, \
+                         HW, C, Cr, mask_out, (const bf16_t*)bn_y, bn_coef, (unsigned long long*)bn_slab); } while (0)
+#define SE_FUSED_D(R_) do { if (nreg == 2) SE_FUSED_K(R_, 2, 0); else if (nlds == 0) SE_FUSED_K(R_, 4, 0); else if (nlds == 2) SE_FUSED_K(R_, 4, 2); \
+      else if (nlds == 4) SE_FUSED_K(R_, 4, 4); else SE_FUSED_K(R_, 4, 6); } while (0)
     const int nit = (HW + nt / cvh - 1) / (nt / cvh);          // vectors a thread visits per phase
     const int nreg = !dtype || se_bwd_nreg_off() ? 0 : nit <= 2 ? 2 : 4;       // (8 / 12 kept vectors spill at the 128 registers a 1024-thread workgroup leaves a wave)
-    if (dtype && nreg) {
-      if (bn_slab) { if (nreg == 2) SE_FUSED_R(2); else SE_FUSED_R(4); }
-      else         { if (nreg == 2) SE_FUSED_P(2); else SE_FUSED_P(4); }
-    }
+    // vectors parked in LDS on top (1024-thread form only: 16 KB each next to the 34 KB of scratch; 6 fill a CU's 160 KB)
+    const int nlds = (nreg == 4 && nt == 1024 && !se_bwd_nlds_off()) ? (nit <= 4 ? 0 : nit <= 6 ? 2 : nit <= 8 ? 4 : 6) : 0;
+    if (dtype && nreg) { if (bn_slab) SE_FUSED_D(true); else SE_FUSED_D(false); }
     else if (dtype) { if (bn_slab) SE_FUSED(bf16_t, true); else SE_FUSED(bf16_t, false); }
     else { if (bn_slab) SE_FUSED(float, true); else SE_FUSED(float, false); }
-#undef SE_FUSED_R
-#undef SE_FUSED_P
+#undef SE_FUSED_K
+#undef SE_FUSED_D
 #undef SE_FUSED
     launch_se_wgrad(dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr, st);
     VQA_LAUNCH_CHECK(); return VQA_OK;
