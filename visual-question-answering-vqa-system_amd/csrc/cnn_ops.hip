@@ -767,7 +767,8 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const T* __restrict__
 // the NREG = 0 kernel's: bit-identical dx and sums.
 // NLDS > 0: the next NLDS vectors are parked in LDS between the phases (16 bytes per thread and vector behind the scratch region;
 // one workgroup per CU is resident anyway at these register counts): 10 of a thread's 13 / 25 vectors at stages 2 / 1.
-template <typename T, bool BNRED, int NREG = 0, int NLDS = 0>
+// TAILM: phase 1 also leaves ONE BYTE of [x > 0] per re-read vector in LDS, so phase 2 re-reads dout only (x was read for its signs).
+template <typename T, bool BNRED, int NREG = 0, int NLDS = 0, bool TAILM = false>
 __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ w1,
                                                            const float* __restrict__ w2, const float* __restrict__ hidden,
                                                            const float* __restrict__ scale, float* __restrict__ dz2, float* __restrict__ dh,
@@ -790,6 +791,7 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
   unsigned mbits[NREG > 0 ? (NREG + 3) / 4 : 1];          // [x > 0] of the vectors kept in registers, 8 bits each
   u32x4* dl = reinterpret_cast<u32x4*>(sh + ((blockDim.x * VEC + 3 * C + Cr + 3) & ~3));      // [NLDS][NT] parked vectors ...
   unsigned char* dm = reinterpret_cast<unsigned char*>(dl + NLDS * blockDim.x);              // ... and their [x > 0] bytes
+  unsigned char* dmt = dm + NLDS * blockDim.x;                                               // TAILM: [x > 0] bytes of the re-read vectors
   {
     int p = myr;
     if constexpr (NREG > 0) {
@@ -840,17 +842,32 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
       }
       p = myr + NKEEP * lanes_r;
     }
+    int q = 0;
     for (; p + lanes_r < HW; p += 2 * lanes_r) {
       const size_t o0 = base + (size_t)p * C, o1 = base + (size_t)(p + lanes_r) * C;
       Vec16<T> d0 = ldg16(dout + o0), v0 = ldg16(x + o0), d1 = ldg16(dout + o1), v1 = ldg16(x + o1);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) s[j] += d0.get(j) * v0.get(j) + d1.get(j) * v1.get(j);
+      if constexpr (TAILM) {
+        unsigned m0 = 0u, m1 = 0u;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { m0 |= (v0.get(j) > 0.f ? 1u : 0u) << j; m1 |= (v1.get(j) > 0.f ? 1u : 0u) << j; }
+        dmt[q * blockDim.x + threadIdx.x] = (unsigned char)m0; dmt[(q + 1) * blockDim.x + threadIdx.x] = (unsigned char)m1;
+        q += 2;
+      }
     }
     for (; p < HW; p += lanes_r) {
       const size_t off = base + (size_t)p * C;
       Vec16<T> d = ldg16(dout + off), v = ldg16(x + off);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) s[j] += d.get(j) * v.get(j);
+      if constexpr (TAILM) {
+        unsigned m0 = 0u;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) m0 |= (v.get(j) > 0.f ? 1u : 0u) << j;
+        dmt[q * blockDim.x + threadIdx.x] = (unsigned char)m0;
+        q += 1;
+      }
     }
   }
 #pragma unroll
@@ -926,16 +943,19 @@ __global__ __launch_bounds__(1024) void se_bwd_fused_kernel(const T* __restrict_
       }
     }
   }
+  int qt = 0;
 #pragma unroll 2
   for (int p = myr + NKEEP * lanes_r; p < HW; p += lanes_r) {
     const size_t e = base + (size_t)p * C;
     Vec16<T> d = ldg16(dout + e), o, xm, yy;
-    if (mask_out) xm = ldg16(x + e);
+    unsigned mbt = 0xffu;
+    if constexpr (TAILM) { mbt = dmt[qt * blockDim.x + threadIdx.x]; ++qt; }   // (TAILM is only dispatched with mask_out; own bytes: no barrier)
+    else if (mask_out) xm = ldg16(x + e);
     if constexpr (BNRED) yy = ldg16(bn_y + e);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float v = fmaf(d.get(j), sc[j], dp[j]);
-      if (mask_out && !(xm.get(j) > 0.f)) v = 0.f;
+      if (TAILM ? !((mbt >> j) & 1u) : (mask_out && !(xm.get(j) > 0.f))) v = 0.f;
       o.set(j, v);
       if constexpr (BNRED) { const float g = o.get(j); sg[j] += g; sx[j] += g * (yy.get(j) - bmean[j]) * binv[j]; }
     }
@@ -1386,9 +1406,10 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
     const size_t shm2 = ((size_t)nt * VEC + 3 * C + Cr) * 4;
 #define SE_FUSED(TT, R) hipLaunchKernelGGL((se_bwd_fused_kernel<TT, R>), dim3(B), dim3(nt), shm2, st, (const TT*)dout, (const TT*)x, w1, w2, hidden, scale, \
     dz2, dh, dpool, (TT*)dx, HW, C, Cr, mask_out, (const TT*)bn_y, bn_coef, (unsigned long long*)bn_slab)
-#define SE_FUSED_K(R_, NR, NL) do { \
-      const size_t shl = ((shm2 + 15) & ~(size_t)15) + (size_t)(NL) * nt * 17; \
-      auto kfn = se_bwd_fused_kernel<bf16_t, R_, NR, NL>; \
+#define SE_FUSED_K(R_, NR, NL) do { if (tailm) SE_FUSED_KT(R_, NR, NL, true); else SE_FUSED_KT(R_, NR, NL, false); } while (0)
+#define SE_FUSED_KT(R_, NR, NL, TM) do { \
+      const size_t shl = ((shm2 + 15) & ~(size_t)15) + (size_t)(NL) * nt * 17 + ((TM) ? (size_t)ntail * nt : 0); \
+      auto kfn = se_bwd_fused_kernel<bf16_t, R_, NR, NL, TM>; \
       if (shl > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl); \
       hipLaunchKernelGGL(kfn, dim3(B), dim3(nt), shl, st, (const bf16_t*)dout, (const bf16_t*)x, w1, w2, hidden, scale, dz2, dh, dpool, (bf16_t*)dx, \
                          HW, C, Cr, mask_out, (const bf16_t*)bn_y, bn_coef, (unsigned long long*)bn_slab); } while (0)
@@ -1398,10 +1419,15 @@ int vqa_se_bwd(int dtype, const void* dout, const void* x, const float* w1, cons
     const int nreg = !dtype || se_bwd_nreg_off() ? 0 : nit <= 2 ? 2 : 4;       // (8 / 12 kept vectors spill at the 128 registers a 1024-thread workgroup leaves a wave)
     // vectors parked in LDS on top (1024-thread form only: 16 KB each next to the 34 KB of scratch; 6 fill a CU's 160 KB)
     const int nlds = (nreg == 4 && nt == 1024 && !se_bwd_nlds_off()) ? (nit <= 4 ? 0 : nit <= 6 ? 2 : nit <= 8 ? 4 : 6) : 0;
+    // one byte of [x > 0] per re-read vector and thread in LDS instead of the second read of x, where it fits beside the rest
+    const int ntail = nit - nreg - nlds > 0 ? nit - nreg - nlds : 0;
+    const bool tailm = nreg == 4 && mask_out && ntail > 0 && !se_bwd_nlds_off() &&
+                       ((shm2 + 15) & ~(size_t)15) + (size_t)nlds * nt * 17 + (size_t)ntail * nt <= 156 * 1024;
     if (dtype && nreg) { if (bn_slab) SE_FUSED_D(true); else SE_FUSED_D(false); }
     else if (dtype) { if (bn_slab) SE_FUSED(bf16_t, true); else SE_FUSED(bf16_t, false); }
     else { if (bn_slab) SE_FUSED(float, true); else SE_FUSED(float, false); }
 #undef SE_FUSED_K
+#undef SE_FUSED_KT
 #undef SE_FUSED_D
 #undef SE_FUSED
     launch_se_wgrad(dz2, hidden, dh, pooled, dw1, dw2, B, C, Cr, st);
